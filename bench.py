@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- lattice configs/sec of forward + log|det J| (Posterior.sample_ minus the prior
+draw) on BASELINE.json's headline workload: 32^4 phi^4 lattice, 8 RQ-spline coupling layers
+(knots_len 16, ConvAct hidden [8,8], kernel 3, tanh), batch 1024 per GPU, fp32, synthetic
+inputs already resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU; the batch shards over ranks with no data-path collective (forward /
+sampling needs none), so scaling is weak: every rank runs the full per-GPU batch.  Rank 0
+prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     : the fused RQ-spline coupling kernel (HBM-bound), HIP-event timed in here
+  cpu_baseline : the CPU oracle (oracle/nf_oracle.py, kind "port") on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("NORMFLOW_AMD_KEEP_TORCH_DEFAULTS", "1")   # bench manages dtype/device itself
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1024, help="batch per GPU")
+    ap.add_argument("--lattice", type=str, default="32,32,32,32")
+    ap.add_argument("--layers", type=int, default=8)
+    ap.add_argument("--knots", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--kernel-reps", type=int, default=10)
+    return ap.parse_args()
+
+
+def build_net(lattice, layers, m, dev, seed):
+    from normflow__amd.mask import EvenOddMask
+    from normflow__amd.nn import ConvAct, RQSplineCoupling_, ModuleList_
+    torch.manual_seed(seed)
+    d = len(lattice)
+    nets = [ConvAct(1, 3 * m - 2, 3, conv_dim=d, hidden_sizes=[8, 8], acts=['tanh', 'tanh', None])
+            for _ in range(layers)]
+    cpl = RQSplineCoupling_(nets, mask=EvenOddMask(shape=lattice), xlim=(-5.0, 5.0), ylim=(-5.0, 5.0),
+                            extrap={'left': 'linear', 'right': 'linear'})
+    net_ = ModuleList_([cpl])
+    net_.to(device=dev, dtype=torch.float32)
+    # rescale the last conv so that the coupling logits have std ~ 0.5
+    with torch.no_grad():
+        probe = torch.randn((1, 1) + tuple(lattice), device=dev, dtype=torch.float32)
+        for net in cpl.nets:
+            last = [mod for mod in net if any(True for _ in mod.parameters())][-1]
+            std = float(net(probe).std())
+            for p in last.parameters():
+                p.mul_(0.5 / max(std, 1e-6))
+    return net_, cpl
+
+
+def time_rqs_kernel(cpl, lattice, m, dev, reps, layout_pair):
+    """Average duration of one nf_rqs_fwd launch on the slab shape the pipeline uses; HIP events
+    on the launch stream (the kernels are launched on torch's current stream)."""
+    from normflow__amd import _hip
+    from normflow__amd.nn.scalar import couplings_ as cp
+    V = 1
+    for n in lattice:
+        V *= n
+    C = 3 * m - 2
+    Vp = V // 2 if layout_pair else V
+    slab = max(1, min(64, cp.PARAM_SLAB_BYTES // (C * V * 4)))
+    act = cpl.mask.activity(0).reshape(-1).to(dev)
+    g = torch.Generator(device=dev).manual_seed(99)
+    x = torch.randn(slab, V, device=dev, dtype=torch.float32, generator=g) * act.float()
+    params = 0.5 * torch.randn(slab, C, Vp, device=dev, dtype=torch.float32, generator=g)
+    opts = _hip.make_rqs_opts(m, (-5.0, 5.0), (-5.0, 5.0), {'left': 'linear', 'right': 'linear'},
+                              _hip.LAYOUT_PAIR if layout_pair else _hip.LAYOUT_FULL)
+    for _ in range(2):
+        _hip.RQSCouplingFn.apply(x, params, None, act, opts, False)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        _hip.RQSCouplingFn.apply(x, params, None, act, opts, False)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    algo_bytes = slab * (V // 2) * (C + 2) * 4          # B*(V/2)*(C+2)*sizeof
+    return dict(seconds=sec, slab=slab, algo_bytes=algo_bytes, gbs=algo_bytes / sec / 1e9)
+
+
+def cpu_baseline(cpl, lattice, m, budget_s):
+    """The CPU oracle restatement (plain PyTorch CPU ops, all host threads, fp32) on a bounded
+    sample of the same workload: whole coupling layers of the bench network at batch 1."""
+    from oracle import nf_oracle as O
+    nthreads = os.cpu_count() or 1
+    torch.set_num_threads(nthreads)
+    nets = []
+    for net in cpl.nets:
+        convs = [mod for mod in net if any(True for _ in mod.parameters())]
+        layers = []
+        for c in convs:
+            w = c.weight.detach().float().cpu().contiguous()
+            layers.append((w, c.bias.detach().float().cpu()))
+        nets.append(lambda t, layers=layers: O.conv_act(t, layers, ['tanh', 'tanh', None]))
+    g = torch.Generator(device='cpu').manual_seed(4321)
+    x = torch.randn((1,) + tuple(lattice), generator=g, dtype=torch.float32, device='cpu')
+    opts = dict(xlim=(-5.0, 5.0), ylim=(-5.0, 5.0), extrap={'left': 'linear', 'right': 'linear'})
+    done, t0 = 0, time.time()
+    with torch.no_grad():
+        masks = [O.channel_mask(lattice, c, dtype=torch.float32) for c in (0, 1)]
+        parts = [x * masks[0], x * masks[1]]
+        log0 = 0
+        for k, net in enumerate(nets):
+            p = k % 2
+            out = net(parts[1 - p].unsqueeze(1))
+            parts[p], log0 = O.rqs_coupling_atom(parts[p], out, masks[p], log0=log0, **opts)
+            done += 1
+            if time.time() - t0 > budget_s:
+                break
+    dt = time.time() - t0
+    per_cfg = dt / done * len(nets)
+    return dict(value=1.0 / per_cfg, unit="configs/s", cores=nthreads, kind="port",
+                sample=f"{done} of {len(nets)} coupling layers (conv stack + RQ spline + log-det) of the bench "
+                       f"network at batch 1, fp32, torch CPU ops on {nthreads} threads, {dt:.1f} s; "
+                       f"extrapolated linearly to {len(nets)} layers")
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the hot path)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # RCCL
+    import normflow__amd  # noqa: F401
+    lattice = tuple(int(s) for s in a.lattice.split(","))
+    net_, cpl = build_net(lattice, a.layers, a.knots, dev, seed=2024)       # same weights on all ranks
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.randn((a.batch,) + lattice, device=dev, dtype=torch.float32, generator=g)
+
+    def step():
+        with torch.no_grad():
+            return net_(x)
+
+    for _ in range(a.warmup):
+        y, logJ = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        y, logJ = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(logJ).all()) and bool(torch.isfinite(y).all())
+
+    if rank == 0:
+        pipeline_pair = False     # the layout the timed pipeline feeds the kernel with
+        kt = time_rqs_kernel(cpl, lattice, a.knots, dev, a.kernel_reps, pipeline_pair)
+        kt_pair = time_rqs_kernel(cpl, lattice, a.knots, dev, a.kernel_reps, True)
+        cfgs = a.batch * world * a.steps
+        line = {
+            "metric": "lattice configs/sec (forward+logdet)", "value": cfgs / elapsed, "unit": "configs/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{'x'.join(map(str, lattice))} phi^4 lattice, {a.layers} RQ-spline coupling "
+                                   f"layers (knots_len {a.knots}, ConvAct 1-8-8-{3*a.knots-2}, k=3, tanh), "
+                                   f"batch {a.batch} per GPU, forward + log|det J|, no_grad",
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}"},
+            "roofline": {"kernel": "nf::rqs_kernel<float,16,fwd>" + ("<pair>" if pipeline_pair else "<full>"),
+                         "bound": "hbm", "achieved": kt["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": kt["gbs"] / HBM_PEAK_GBS, "traffic": None,
+                         "launch_ms": 1e3 * kt["seconds"], "slab_batch": kt["slab"],
+                         "algorithmic_bytes_per_launch": kt["algo_bytes"],
+                         "pair_layout_variant": {"achieved": kt_pair["gbs"], "frac": kt_pair["gbs"] / HBM_PEAK_GBS,
+                                                 "launch_ms": 1e3 * kt_pair["seconds"]}},
+        }
+        if not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cpl, lattice, a.knots, a.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

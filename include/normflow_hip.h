@@ -1,0 +1,170 @@
+/* normflow_hip.h -- C ABI of libnormflow_hip.so (gfx950 / MI355X).
+ *
+ * The drop-in boundary for the coupling-layer hot path of jkomijani/normflow_.
+ * The reference has no FFI of its own (it is pure Python on eager aten ops), so
+ * each entry point replaces an *eager op chain* of the reference; the file:line
+ * of that chain is cited per function (paths relative to the reference root).
+ * INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Rules of the boundary
+ *   - every pointer is a DEVICE pointer owned by the caller (a torch tensor's
+ *     data_ptr(), a hipMalloc'd buffer ...); the library never allocates, frees
+ *     or synchronises; scratch space is passed in (`workspace`), its size is
+ *     given by nf_workspace_bytes();
+ *   - every launch goes to the `stream` argument (a hipStream_t passed as void*);
+ *   - every function returns 0 on success, a negative NF_E* code otherwise, and
+ *     never throws; nf_last_error_string() describes the last failure of the
+ *     calling thread;
+ *   - tensors are dense and row-major.  B = batch, V = number of lattice sites,
+ *     C = channels of raw net output per site.  `dtype` selects the arithmetic
+ *     and storage type of all floating tensors of a call.
+ *
+ * Site activity ("checkerboard masking", src/mask/mask.py:17-61) is given by a
+ * byte mask of V entries: 1 = the site is transformed by this layer ("active"),
+ * 0 = it is frozen.  Two layouts of the per-site parameter tensor exist:
+ *   NF_LAYOUT_FULL : params is (B, C, V); entries at frozen sites are ignored;
+ *   NF_LAYOUT_PAIR : params is (B, C, V/2): the sites are taken in aligned pairs
+ *                    (2h, 2h+1), exactly one site of every pair is active (true
+ *                    for an even-odd mask whose fastest axis is even), and column
+ *                    h holds the parameters of that pair's active site.  This is
+ *                    the HBM-efficient layout: no parameter bytes are read for
+ *                    frozen sites.
+ */
+#ifndef NORMFLOW_HIP_H
+#define NORMFLOW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NF_VERSION 100 /* 0.1.0 */
+
+enum nf_dtype { NF_F32 = 0, NF_F64 = 1 };
+enum nf_layout { NF_LAYOUT_FULL = 0, NF_LAYOUT_PAIR = 1 };
+enum nf_extrap { NF_EXTRAP_NONE = 0, NF_EXTRAP_LINEAR = 1, NF_EXTRAP_ANTI = 2 };
+enum nf_status {
+  NF_OK = 0,
+  NF_EINVAL = -1,    /* bad argument (null pointer, bad size, unsupported option) */
+  NF_EWORKSPACE = -2,/* workspace too small */
+  NF_ELAUNCH = -3    /* hip launch error */
+};
+
+/* Options of one rational-quadratic spline family
+ * (RQSplineCoupling_.__init__, src/nn/scalar/couplings_.py:159-176). */
+typedef struct nf_rqs_opts {
+  int32_t m;            /* knots per spline; C = 3m-2, or 2m-1 / m with fixed knots */
+  int32_t extrap_left;  /* nf_extrap */
+  int32_t extrap_right; /* nf_extrap */
+  int32_t layout;       /* nf_layout of `params` (and of grad_params) */
+  double xlo, xhi, ylo, yhi;
+  const void *fixed_knots_x; /* optional device array of m values (dtype), or NULL */
+  const void *fixed_knots_y; /* optional device array of m values (dtype), or NULL */
+} nf_rqs_opts;
+
+/* Strides (in elements) from one batch entry to the next; 0 selects the dense
+ * default.  They exist so that one data channel of a multi-channel tensor
+ * (MultiRQSplineCoupling_, couplings_.py:279-436) can be addressed in place. */
+typedef struct nf_strides {
+  int64_t x_batch;      /* default V            */
+  int64_t y_batch;      /* default V            */
+  int64_t params_batch; /* default C * V or C*V/2 */
+} nf_strides;
+
+int nf_version(void);
+const char *nf_last_error_string(void);
+
+/* Bytes of scratch needed by any coupling / distconv call on a (B, V) problem. */
+size_t nf_workspace_bytes(int64_t B, int64_t V);
+
+/* ---- K2/K3: rational-quadratic spline coupling -----------------------------
+ * Replaces, fused in one pass: knot construction (couplings_.py:211-262:
+ * split, softmax, cumsum, scale/shift, softplus(beta=ln2)), boundary
+ * augmentation (src/lib/spline/spline.py:458-532), bin search (:154-172),
+ * segment evaluation (:185-220) or inversion (:222-287), purify + log +
+ * per-sample sum (couplings_.py:186-188, src/nn/_core.py:38-42).
+ *
+ *   x       (B, V)  input field; only active sites are read
+ *   params  (B, C, V) or (B, C, V/2) raw net output (logits)
+ *   mask    (V) bytes, 1 = active
+ *   log0    (B) or NULL (treated as 0)
+ *   y       (B, V)  out: transformed value at active sites, 0 at frozen sites
+ *   logj    (B)     out: log0 + sum over active sites of log|dy/dx|
+ * nf_rqs_inv is the inverse map (y -> x) and adds log|dx/dy|; it uses the
+ * cancellation-free root 2 a0 / (-a1 + sqrt(a1^2 - 4 a0 a2)).
+ */
+int nf_rqs_fwd(const void *x, const void *params, const uint8_t *mask, const void *log0,
+               void *y, void *logj, int64_t B, int64_t V, const nf_rqs_opts *opts,
+               const nf_strides *strides, void *workspace, size_t workspace_bytes,
+               int dtype, void *stream);
+int nf_rqs_inv(const void *y, const void *params, const uint8_t *mask, const void *log0,
+               void *x, void *logj, int64_t B, int64_t V, const nf_rqs_opts *opts,
+               const nf_strides *strides, void *workspace, size_t workspace_bytes,
+               int dtype, void *stream);
+
+/* Vector-Jacobian products of the two maps above (what autograd derives from the
+ * eager chain in the reference; needed by Fitter.step, src/_normflowcore.py:288).
+ *   grad_out  (B, V)  cotangent of the value output
+ *   grad_logj (B)     cotangent of the log-Jacobian output
+ *   grad_in   (B, V)  out: cotangent of the value input (0 at frozen sites)
+ *   grad_params       out: same shape/layout as params (0 at frozen sites)
+ * nf_rqs_fwd_vjp takes the forward INPUT x; nf_rqs_inv_vjp takes the inverse's
+ * OUTPUT x (= the point on the x axis), so neither recomputes a root.
+ */
+int nf_rqs_fwd_vjp(const void *x, const void *params, const uint8_t *mask,
+                   const void *grad_out, const void *grad_logj, void *grad_in,
+                   void *grad_params, int64_t B, int64_t V, const nf_rqs_opts *opts,
+                   const nf_strides *strides, int dtype, void *stream);
+int nf_rqs_inv_vjp(const void *x, const void *params, const uint8_t *mask,
+                   const void *grad_out, const void *grad_logj, void *grad_in,
+                   void *grad_params, int64_t B, int64_t V, const nf_rqs_opts *opts,
+                   const nf_strides *strides, int dtype, void *stream);
+
+/* ---- K1: affine / shift coupling --------------------------------------------
+ * Replaces couplings_.py:123-139 (affine: chunk, 2 purify, abs, exp, fma, sum)
+ * and :110-116 (shift).  params is (B, 2, .) = (t, s) for affine, (B, 1, .) = t
+ * for shift (n_ch selects).  fwd: y = t + x e^{-|s|}, logj = log0 - sum|s|;
+ * inv: x = (y - t) e^{|s|}, logj = log0 + sum|s|.
+ */
+int nf_affine_fwd(const void *x, const void *params, const uint8_t *mask, const void *log0,
+                  void *y, void *logj, int64_t B, int64_t V, int n_ch, int layout,
+                  void *workspace, size_t workspace_bytes, int dtype, void *stream);
+int nf_affine_inv(const void *y, const void *params, const uint8_t *mask, const void *log0,
+                  void *x, void *logj, int64_t B, int64_t V, int n_ch, int layout,
+                  void *workspace, size_t workspace_bytes, int dtype, void *stream);
+/* `inverse` selects which map is differentiated; `v` is that map's input. */
+int nf_affine_vjp(const void *v, const void *params, const uint8_t *mask,
+                  const void *grad_out, const void *grad_logj, void *grad_in,
+                  void *grad_params, int64_t B, int64_t V, int n_ch, int layout,
+                  int inverse, int dtype, void *stream);
+
+/* ---- K4: DistConvertor_ = Expit_ -> SplineNet_ (shared knots) -> Logit_ ------
+ * Replaces src/nn/scalar/modules_.py:93-114, 277-302, 333-358 with ONE pass over
+ * the field.  The spline is shared by all sites; its K knots, already augmented for
+ * the boundary condition (src/lib/spline/spline.py:458-532; O(m) host-side work on
+ * the learned logits), are staged in LDS by the kernels.
+ *
+ *   knots   3*K values of dtype: x[0..K) | y[0..K) | d[0..K), K <= 512
+ *   stages  bit0 = expit before, bit1 = spline, bit2 = logit after
+ *           (DistConvertor_ = 7, a bare SplineNet_ = 2)
+ *   inverse runs the inverse chain (the reversed list of inverted stages,
+ *           src/nn/_core.py:69-72)
+ *   x, y    (B, V);  log0, logj (B)
+ */
+int nf_distconv(const void *x, const void *knots, int K, const void *log0, void *y, void *logj,
+                int64_t B, int64_t V, int stages, int inverse, void *workspace,
+                size_t workspace_bytes, int dtype, void *stream);
+/* VJP: grad_in (B,V) and grad_knots (3K DOUBLES, summed over the whole field,
+ * overwritten by the call).  `v` is the forward chain's input (inverse=0) or the
+ * inverse chain's OUTPUT (inverse=1). */
+int nf_distconv_vjp(const void *v, const void *knots, int K, const void *grad_out,
+                    const void *grad_logj, void *grad_in, double *grad_knots, int64_t B,
+                    int64_t V, int stages, int inverse, void *workspace,
+                    size_t workspace_bytes, int dtype, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NORMFLOW_HIP_H */

@@ -1,0 +1,349 @@
+"""ctypes binding of libnormflow_hip.so (the C ABI in include/normflow_hip.h) and the
+`torch.autograd.Function`s that put its kernels behind differentiable tensor ops.
+
+There is NO fallback here: if the shared library is missing, or a tensor is not on a
+HIP device, the call raises.  PyTorch is used for device memory, the current
+stream and autograd bookkeeping only.
+"""
+import ctypes as C
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnormflow_hip.so")
+
+NF_F32, NF_F64 = 0, 1
+LAYOUT_FULL, LAYOUT_PAIR = 0, 1
+EXTRAP = {None: 0, 'none': 0, 'linear': 1, 'anti': 2, 'anti-periodic': 2}
+
+
+class NormflowHipError(RuntimeError):
+    pass
+
+
+class RqsOpts(C.Structure):
+    _fields_ = [("m", C.c_int32), ("extrap_left", C.c_int32), ("extrap_right", C.c_int32),
+                ("layout", C.c_int32), ("xlo", C.c_double), ("xhi", C.c_double),
+                ("ylo", C.c_double), ("yhi", C.c_double),
+                ("fixed_knots_x", C.c_void_p), ("fixed_knots_y", C.c_void_p)]
+
+
+class Strides(C.Structure):
+    _fields_ = [("x_batch", C.c_int64), ("y_batch", C.c_int64), ("params_batch", C.c_int64)]
+
+
+_P, _I64, _I, _SZ, _D = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_double
+_MAP_ARGS = [_P, _P, _P, _P, _P, _P, _I64, _I64, C.POINTER(RqsOpts), C.POINTER(Strides), _P, _SZ, _I, _P]
+_VJP_ARGS = [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, C.POINTER(RqsOpts), C.POINTER(Strides), _I, _P]
+PROTOTYPES = {
+    "nf_version": (C.c_int, []),
+    "nf_last_error_string": (C.c_char_p, []),
+    "nf_workspace_bytes": (_SZ, [_I64, _I64]),
+    "nf_rqs_fwd": (_I, _MAP_ARGS),
+    "nf_rqs_inv": (_I, _MAP_ARGS),
+    "nf_rqs_fwd_vjp": (_I, _VJP_ARGS),
+    "nf_rqs_inv_vjp": (_I, _VJP_ARGS),
+    "nf_affine_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _P, _SZ, _I, _P]),
+    "nf_affine_inv": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _P, _SZ, _I, _P]),
+    "nf_affine_vjp": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _I, _I, _P]),
+    "nf_distconv": (_I, [_P, _P, _I, _P, _P, _P, _I64, _I64, _I, _I, _P, _SZ, _I, _P]),
+    "nf_distconv_vjp": (_I, [_P, _P, _I, _P, _P, _P, _P, _I64, _I64, _I, _I, _P, _SZ, _I, _P]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load the HIP library once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise NormflowHipError(
+                    f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                    "g.build()'` or `make -C normflow__amd/csrc` (hipcc --offload-arch=gfx950). "
+                    "normflow__amd has no CPU or eager-PyTorch fallback for its kernels.")
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in PROTOTYPES.items():
+                fn = getattr(lib, name)
+                fn.restype, fn.argtypes = res, args
+            _lib = lib
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load().nf_last_error_string().decode("utf-8", "replace")
+        raise NormflowHipError(f"{what} failed (code {rc}): {msg}")
+
+
+def _dtype_code(t):
+    if t.dtype == torch.float32:
+        return NF_F32
+    if t.dtype == torch.float64:
+        return NF_F64
+    raise TypeError(f"normflow__amd kernels support float32 and float64, got {t.dtype}")
+
+
+def _require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise NormflowHipError(
+                "normflow__amd kernels need tensors on an MI355X (torch device 'cuda'); got a "
+                f"{t.device} tensor and there is no CPU fallback")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_ws_cache = {}
+
+
+def _workspace(B, V, device):
+    """Per-device scratch buffer for the per-workgroup log-det partials (grown on demand)."""
+    need = load().nf_workspace_bytes(B, V)
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(max(need, 1 << 22), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _log0_tensor(log0, like, B):
+    """log0 may be the python number 0 (nn/_core.py:25 default) or a (B,) tensor."""
+    if torch.is_tensor(log0):
+        if log0.dim() == 0:
+            log0 = log0.expand(B)
+        return log0.to(dtype=like.dtype, device=like.device).contiguous()
+    if log0 == 0:
+        return None
+    return torch.full((B,), float(log0), dtype=like.dtype, device=like.device)
+
+
+MAX_B = 32768  # the batch is the grid's y extent; larger batches are cut into slabs
+
+
+# =============================================================================== RQS
+def make_rqs_opts(m, xlim, ylim, extrap, layout):
+    extrap = extrap or {}
+    for side in ('left', 'right'):
+        if extrap.get(side) not in EXTRAP:
+            raise NotImplementedError(f"extrapolation {extrap.get(side)!r} is not supported "
+                                      "(supported: None, 'linear', 'anti')")
+    return RqsOpts(int(m), EXTRAP[extrap.get('left')], EXTRAP[extrap.get('right')], int(layout),
+                   float(xlim[0]), float(xlim[1]), float(ylim[0]), float(ylim[1]), None, None)
+
+
+def _rqs_call(fn_name, v, params, mask, log0, opts, strides, B, V):
+    lib = load()
+    out = torch.empty_like(v)
+    logj = torch.empty(B, dtype=v.dtype, device=v.device)
+    ws = _workspace(min(B, MAX_B), V, v.device)
+    for b0 in range(0, B, MAX_B):
+        b1 = min(B, b0 + MAX_B)
+        l0 = log0[b0:b1] if log0 is not None else None
+        _check(getattr(lib, fn_name)(_ptr(v[b0:b1]), _ptr(params[b0:b1]), _ptr(mask), _ptr(l0),
+                                      _ptr(out[b0:b1]), _ptr(logj[b0:b1]), b1 - b0, V, C.byref(opts),
+                                      C.byref(strides) if strides is not None else None, _ptr(ws),
+                                      ws.numel(), _dtype_code(v), _stream()), fn_name)
+    return out, logj
+
+
+def _rqs_vjp_call(fn_name, x, params, mask, gout, glogj, opts, strides, B, V):
+    lib = load()
+    gin = torch.empty_like(x)
+    gpar = torch.empty_like(params)
+    for b0 in range(0, B, MAX_B):
+        b1 = min(B, b0 + MAX_B)
+        _check(getattr(lib, fn_name)(_ptr(x[b0:b1]), _ptr(params[b0:b1]), _ptr(mask), _ptr(gout[b0:b1]),
+                                      _ptr(glogj[b0:b1]), _ptr(gin[b0:b1]), _ptr(gpar[b0:b1]), b1 - b0, V,
+                                      C.byref(opts), C.byref(strides) if strides is not None else None,
+                                      _dtype_code(x), _stream()), fn_name)
+    return gin, gpar
+
+
+class RQSCouplingFn(torch.autograd.Function):
+    """(value, logJ) of one RQ-spline coupling layer on the active sublattice.
+
+    v: (B, V) field (only active sites are read); params: (B, C, V) or (B, C, V/2) raw
+    logits; mask: (V,) uint8 activity; log0: (B,) tensor or None.
+    """
+
+    @staticmethod
+    def forward(ctx, v, params, log0, mask, opts, inverse):
+        _require_device(v, params, mask, log0)
+        B, V = v.shape
+        v, params = v.contiguous(), params.contiguous()
+        if params.dtype != v.dtype:
+            raise TypeError(f"field is {v.dtype} but net output is {params.dtype}")
+        out, logj = _rqs_call("nf_rqs_inv" if inverse else "nf_rqs_fwd", v, params, mask, log0, opts,
+                              None, B, V)
+        ctx.save_for_backward(out if inverse else v, params, mask)
+        ctx.opts, ctx.inverse, ctx.has_log0 = opts, inverse, log0 is not None
+        return out, logj
+
+    @staticmethod
+    def backward(ctx, gout, glogj):
+        x, params, mask = ctx.saved_tensors
+        B, V = x.shape
+        gin, gpar = _rqs_vjp_call("nf_rqs_inv_vjp" if ctx.inverse else "nf_rqs_fwd_vjp", x, params, mask,
+                                  gout.contiguous(), glogj.contiguous(), ctx.opts, None, B, V)
+        return gin, gpar, (glogj if ctx.has_log0 else None), None, None, None
+
+
+class MultiRQSCouplingFn(torch.autograd.Function):
+    """`n_s` independent splines, one per data channel, addressed in place through batch
+    strides (MultiRQSplineCoupling_).  v: (B, n_s, V); params: (B, n_s*C, Vp)."""
+
+    @staticmethod
+    def forward(ctx, v, params, log0, mask, opts_list, inverse):
+        _require_device(v, params, mask, log0)
+        B, ns, V = v.shape
+        v, params = v.contiguous(), params.contiguous()
+        Ctot, Vp = params.shape[1], params.shape[2]
+        Cs = Ctot // ns
+        out = torch.empty_like(v)
+        lib = load()
+        fn = lib.nf_rqs_inv if inverse else lib.nf_rqs_fwd
+        ws = _workspace(B, V, v.device)
+        esz = v.element_size()
+        st = Strides(ns * V, ns * V, Ctot * Vp)
+        logj = log0
+        for i, opts in enumerate(opts_list):
+            nxt = torch.empty(B, dtype=v.dtype, device=v.device)
+            _check(fn(C.c_void_p(v.data_ptr() + i * V * esz), C.c_void_p(params.data_ptr() + i * Cs * Vp * esz),
+                      _ptr(mask), _ptr(logj), C.c_void_p(out.data_ptr() + i * V * esz), _ptr(nxt), B, V,
+                      C.byref(opts), C.byref(st), _ptr(ws), ws.numel(), _dtype_code(v), _stream()),
+                   "nf_rqs (multi)")
+            logj = nxt
+        ctx.save_for_backward(out if inverse else v, params, mask)
+        ctx.opts_list, ctx.inverse, ctx.has_log0 = opts_list, inverse, log0 is not None
+        return out, logj
+
+    @staticmethod
+    def backward(ctx, gout, glogj):
+        x, params, mask = ctx.saved_tensors
+        B, ns, V = x.shape
+        Ctot, Vp = params.shape[1], params.shape[2]
+        Cs = Ctot // ns
+        gout, glogj = gout.contiguous(), glogj.contiguous()
+        gin, gpar = torch.empty_like(x), torch.empty_like(params)
+        lib = load()
+        fn = lib.nf_rqs_inv_vjp if ctx.inverse else lib.nf_rqs_fwd_vjp
+        esz = x.element_size()
+        st = Strides(ns * V, ns * V, Ctot * Vp)
+        for i, opts in enumerate(ctx.opts_list):
+            xo, po = i * V * esz, i * Cs * Vp * esz
+            _check(fn(C.c_void_p(x.data_ptr() + xo), C.c_void_p(params.data_ptr() + po), _ptr(mask),
+                      C.c_void_p(gout.data_ptr() + xo), _ptr(glogj), C.c_void_p(gin.data_ptr() + xo),
+                      C.c_void_p(gpar.data_ptr() + po), B, V, C.byref(opts), C.byref(st), _dtype_code(x),
+                      _stream()), "nf_rqs_vjp (multi)")
+        return gin, gpar, (glogj if ctx.has_log0 else None), None, None, None
+
+
+# ============================================================================ affine
+class AffineCouplingFn(torch.autograd.Function):
+    """Affine (n_ch = 2) or shift (n_ch = 1) coupling on the active sublattice."""
+
+    @staticmethod
+    def forward(ctx, v, params, log0, mask, layout, inverse):
+        _require_device(v, params, mask, log0)
+        B, V = v.shape
+        v, params = v.contiguous(), params.contiguous()
+        if params.dtype != v.dtype:
+            raise TypeError(f"field is {v.dtype} but net output is {params.dtype}")
+        n_ch = params.shape[1]
+        lib = load()
+        out = torch.empty_like(v)
+        logj = torch.empty(B, dtype=v.dtype, device=v.device)
+        ws = _workspace(min(B, MAX_B), V, v.device)
+        fn = lib.nf_affine_inv if inverse else lib.nf_affine_fwd
+        for b0 in range(0, B, MAX_B):
+            b1 = min(B, b0 + MAX_B)
+            l0 = log0[b0:b1] if log0 is not None else None
+            _check(fn(_ptr(v[b0:b1]), _ptr(params[b0:b1]), _ptr(mask), _ptr(l0), _ptr(out[b0:b1]),
+                      _ptr(logj[b0:b1]), b1 - b0, V, n_ch, layout, _ptr(ws), ws.numel(), _dtype_code(v),
+                      _stream()), "nf_affine")
+        ctx.save_for_backward(v, params, mask)
+        ctx.layout, ctx.inverse, ctx.has_log0 = layout, inverse, log0 is not None
+        return out, logj
+
+    @staticmethod
+    def backward(ctx, gout, glogj):
+        v, params, mask = ctx.saved_tensors
+        B, V = v.shape
+        gout, glogj = gout.contiguous(), glogj.contiguous()
+        gin, gpar = torch.empty_like(v), torch.empty_like(params)
+        lib = load()
+        for b0 in range(0, B, MAX_B):
+            b1 = min(B, b0 + MAX_B)
+            _check(lib.nf_affine_vjp(_ptr(v[b0:b1]), _ptr(params[b0:b1]), _ptr(mask), _ptr(gout[b0:b1]),
+                                     _ptr(glogj[b0:b1]), _ptr(gin[b0:b1]), _ptr(gpar[b0:b1]), b1 - b0, V,
+                                     params.shape[1], ctx.layout, int(ctx.inverse), _dtype_code(v),
+                                     _stream()), "nf_affine_vjp")
+        return gin, gpar, (glogj if ctx.has_log0 else None), None, None, None
+
+
+# ========================================================================== distconv
+STAGE_EXPIT, STAGE_SPLINE, STAGE_LOGIT = 1, 2, 4
+
+
+class DistConvFn(torch.autograd.Function):
+    """Expit_ -> shared-knot spline -> Logit_ (any subset, `stages` bit mask) in one pass.
+
+    v: (B, V); knots: (3, K) augmented knots (x | y | d), differentiable.
+    """
+
+    @staticmethod
+    def forward(ctx, v, knots, log0, stages, inverse):
+        _require_device(v, knots, log0)
+        B, V = v.shape
+        v = v.contiguous()
+        if knots is not None:
+            knots = knots.to(v.dtype).contiguous()
+        K = knots.shape[1] if knots is not None else 0
+        lib = load()
+        out = torch.empty_like(v)
+        logj = torch.empty(B, dtype=v.dtype, device=v.device)
+        ws = _workspace(min(B, MAX_B), V, v.device)
+        for b0 in range(0, B, MAX_B):
+            b1 = min(B, b0 + MAX_B)
+            l0 = log0[b0:b1] if log0 is not None else None
+            _check(lib.nf_distconv(_ptr(v[b0:b1]), _ptr(knots), K, _ptr(l0), _ptr(out[b0:b1]),
+                                   _ptr(logj[b0:b1]), b1 - b0, V, stages, int(inverse), _ptr(ws),
+                                   ws.numel(), _dtype_code(v), _stream()), "nf_distconv")
+        ctx.save_for_backward(out if inverse else v, knots)
+        ctx.stages, ctx.inverse, ctx.has_log0 = stages, inverse, log0 is not None
+        return out, logj
+
+    @staticmethod
+    def backward(ctx, gout, glogj):
+        x, knots = ctx.saved_tensors
+        B, V = x.shape
+        K = knots.shape[1] if knots is not None else 0
+        gout, glogj = gout.contiguous(), glogj.contiguous()
+        gin = torch.empty_like(x)
+        gk = torch.zeros(3, max(K, 1), dtype=torch.float64, device=x.device)
+        lib = load()
+        ws = _workspace(min(B, MAX_B), V, x.device)
+        for b0 in range(0, B, MAX_B):
+            b1 = min(B, b0 + MAX_B)
+            part = torch.zeros(3, max(K, 1), dtype=torch.float64, device=x.device)
+            _check(lib.nf_distconv_vjp(_ptr(x[b0:b1]), _ptr(knots), K, _ptr(gout[b0:b1]), _ptr(glogj[b0:b1]),
+                                       _ptr(gin[b0:b1]), _ptr(part), b1 - b0, V, ctx.stages,
+                                       int(ctx.inverse), _ptr(ws), ws.numel(), _dtype_code(x), _stream()),
+                   "nf_distconv_vjp")
+            gk += part
+        gk = gk.to(knots.dtype) if knots is not None else None
+        return gin, gk, (glogj if ctx.has_log0 else None), None, None

@@ -1,0 +1,514 @@
+// nf_rqs.hip -- K2/K3: fused rational-quadratic-spline coupling kernels for gfx950.
+//
+// One lane = one ACTIVE lattice site.  Per site the kernel reads the C = 3m-2 raw
+// logits the parameter net produced (channel-strided, so every channel read of a
+// wave is one coalesced 256-B / 512-B row), builds the knots in registers (static
+// m) or in an LDS column (runtime m), finds the bin by a predicated scan, evaluates
+// or inverts the rational-quadratic segment, writes the value and reduces log|J|
+// per sample (lane partials -> wave shuffle -> LDS -> one double per workgroup ->
+// finalize kernel; no atomics, bitwise reproducible).
+//
+// Maths restated from the reference (file:line relative to the reference root):
+//   knots      src/nn/scalar/couplings_.py:211-262
+//   boundary   src/lib/spline/spline.py:458-532 ('linear' = tangent-line tails,
+//              'anti' = point reflection through the end knot, done here by
+//              reflecting the argument instead of materialising mirrored knots)
+//   bin search src/lib/spline/spline.py:154-172 (left-bisect + clamp == number of
+//              interior knots strictly below the value)
+//   evaluate   src/lib/spline/spline.py:185-220 ; invert :222-287 (stable root)
+//   log-det    src/nn/scalar/couplings_.py:186-188, src/nn/_core.py:38-42
+#include "nf_internal.h"
+
+namespace nf {
+
+enum { kFwd = 0, kInv = 1 };
+
+struct RqsArgs {
+  const void *x;
+  const void *params;
+  const uint8_t *mask;
+  void *y;
+  double *partial;          // (B, gridDim.x) or null when the VJP runs
+  const void *grad_out;     // VJP only
+  const void *grad_logj;    // VJP only
+  void *grad_in;            // VJP only
+  void *grad_params;        // VJP only
+  int64_t V;                // sites per sample
+  int64_t Vp;               // site extent of params: V (full) or V/2 (pair)
+  int64_t units;            // work units per sample: V (full) or V/2 (pair)
+  int64_t x_bs, y_bs, p_bs; // batch strides (elements)
+  double xlo, xhi, ylo, yhi;
+  int m, el, er, layout, iters;
+};
+
+// ------------------------------------------------------------ parameter columns
+template <typename T, int C> struct RegCol {   // static m: logits live in VGPRs
+  T v[C];
+  __device__ __forceinline__ T &operator[](int i) { return v[i]; }
+};
+template <typename T> struct LdsCol {          // runtime m: one LDS column per lane
+  T *p;                                        // bank = lane % 32 for every row: conflict-free
+  __device__ __forceinline__ T &operator[](int i) const { return p[i * kBlock]; }
+};
+
+template <typename T> struct Pair2;   // two adjacent sites as one 8/16-byte access
+template <> struct Pair2<float> { typedef float2 type; };
+template <> struct Pair2<double> { typedef double2 type; };
+
+template <typename T> struct Site {   // what the scan selects for one site
+  T x0, y0, bw, bh, c0, c1, xe, ye;
+  int j;
+};
+
+// Softmax numerators in place, then the predicated bin scan.  On return a[0..nb)
+// and a[nb..2nb) hold exp(logit - max); sa/sb their sums.
+template <typename T, int MT, bool ON_Y, typename Col>
+__device__ __forceinline__ Site<T> scan_bins(Col &a, int m_rt, T v, T xlo, T W, T ylo, T H, T &sa,
+                                             T &sb) {
+  const int m = MT > 0 ? MT : m_rt;
+  const int nb = m - 1;
+  T amax = a[0], bmax = a[nb];
+#pragma unroll
+  for (int k = 1; k < nb; ++k) {
+    amax = Num<T>::max(amax, a[k]);
+    bmax = Num<T>::max(bmax, a[nb + k]);
+  }
+  sa = T(0);
+  sb = T(0);
+#pragma unroll
+  for (int k = 0; k < nb; ++k) {
+    const T ea = Num<T>::exp2((a[k] - amax) * Num<T>::kLog2e);
+    const T eb = Num<T>::exp2((a[nb + k] - bmax) * Num<T>::kLog2e);
+    a[k] = ea;
+    a[nb + k] = eb;
+    sa += ea;
+    sb += eb;
+  }
+  const T wx = W / sa, wy = H / sb;
+  Site<T> s;
+  T cx = xlo, cy = ylo;
+  s.x0 = xlo; s.y0 = ylo; s.bw = a[0] * wx; s.bh = a[nb] * wy;
+  s.c0 = a[2 * nb]; s.c1 = a[2 * nb + 1]; s.j = 0;
+  cx += s.bw; cy += s.bh;
+#pragma unroll
+  for (int k = 1; k < nb; ++k) {
+    const T wk = a[k] * wx, hk = a[nb + k] * wy;
+    const bool sel = (ON_Y ? cy : cx) < v;   // knot k strictly below the value
+    s.x0 = sel ? cx : s.x0;
+    s.y0 = sel ? cy : s.y0;
+    s.bw = sel ? wk : s.bw;
+    s.bh = sel ? hk : s.bh;
+    s.c0 = sel ? a[2 * nb + k] : s.c0;
+    s.c1 = sel ? a[2 * nb + k + 1] : s.c1;
+    s.j = sel ? k : s.j;
+    cx += wk; cy += hk;
+  }
+  s.xe = cx; s.ye = cy;   // last knot as accumulated (the reference's cumsum end)
+  return s;
+}
+
+// Value and log|derivative| of the map at one site.  INV=false: v is x, returns y
+// and log(dy/dx).  INV=true: v is y, returns x and log(dx/dy) = -log g.
+template <typename T, int MT, bool INV, typename Col>
+__device__ __forceinline__ void rqs_site(Col &a, const RqsArgs &A, T v, T &val, T &logd) {
+  const T xlo = T(A.xlo), W = T(A.xhi) - T(A.xlo), ylo = T(A.ylo), H = T(A.yhi) - T(A.ylo);
+  const T in_lo = INV ? ylo : xlo, in_hi = INV ? ylo + H : xlo + W;
+  const T out_lo = INV ? xlo : ylo, out_hi = INV ? xlo + W : ylo + H;
+  const bool refl_l = (A.el == NF_EXTRAP_ANTI) && (v < in_lo);
+  const bool refl_r = (A.er == NF_EXTRAP_ANTI) && (v > in_hi);
+  v = refl_l ? T(2) * in_lo - v : (refl_r ? T(2) * in_hi - v : v);
+  T sa, sb;
+  const Site<T> s = scan_bins<T, MT, INV>(a, A.m, v, xlo, W, ylo, H, sa, sb);
+  const bool tail_l = (A.el == NF_EXTRAP_LINEAR) && !(in_lo < v);
+  const bool tail_r = (A.er == NF_EXTRAP_LINEAR) && ((INV ? s.ye : s.xe) < v);
+  const T d0 = softplus2(s.c0), d1 = softplus2(s.c1);
+  const T sl = s.bh / s.bw;            // segment slope
+  const T curv = d0 + d1 - T(2) * sl;
+  T th, g;
+  if (!INV) {
+    th = (v - s.x0) / s.bw;
+    const T t1 = th * (T(1) - th);
+    const T den = sl + curv * t1;
+    val = s.y0 + s.bh * (sl * th * th + d0 * t1) / den;
+    const T P = d1 * th * th + T(2) * sl * t1 + d0 * (T(1) - th) * (T(1) - th);
+    g = sl * sl * P / (den * den);
+    val = tail_l ? ylo + d0 * (v - xlo) : (tail_r ? s.ye + d1 * (v - s.xe) : val);
+    g = tail_l ? d0 : (tail_r ? d1 : g);
+    logd = nf_log(g);
+  } else {
+    const T eta = (v - s.y0) / s.bh;
+    const T a2 = -curv * eta + d0 - sl;
+    const T bb = a2 + sl;              // = -a1
+    const T a0 = sl * eta;
+    const T disc = Num<T>::sqrt(Num<T>::max(bb * bb - T(4) * a0 * a2, T(0)));
+    // the root in [0,1], written so that neither branch cancels
+    th = (bb >= T(0)) ? T(2) * a0 / (bb + disc) : (bb - disc) / (T(2) * a2);
+    const T t1 = th * (T(1) - th);
+    const T den = sl + curv * t1;
+    const T P = d1 * th * th + T(2) * sl * t1 + d0 * (T(1) - th) * (T(1) - th);
+    g = sl * sl * P / (den * den);
+    val = s.x0 + s.bw * th;
+    val = tail_l ? xlo + (v - ylo) / d0 : (tail_r ? s.xe + (v - s.ye) / d1 : val);
+    g = tail_l ? d0 : (tail_r ? d1 : g);
+    logd = -nf_log(g);
+  }
+  val = refl_l ? T(2) * out_lo - val : (refl_r ? T(2) * out_hi - val : val);
+}
+
+// VJP at one site.  `x` is the point on the x axis (forward input, or inverse
+// output).  gout / glog are the cotangents of (value, log-det) of the map selected
+// by INV.  Writes the C parameter cotangents back into `a` and returns grad_in.
+template <typename T, int MT, bool INV, typename Col>
+__device__ __forceinline__ T rqs_site_vjp(Col &a, const RqsArgs &A, T x, T gout, T glog) {
+  const int m = MT > 0 ? MT : A.m;
+  const int nb = m - 1;
+  const T xlo = T(A.xlo), W = T(A.xhi) - T(A.xlo), ylo = T(A.ylo), H = T(A.yhi) - T(A.ylo);
+  const bool refl_l = (A.el == NF_EXTRAP_ANTI) && (x < xlo);
+  const bool refl_r = (A.er == NF_EXTRAP_ANTI) && (x > xlo + W);
+  const T sgn = (refl_l || refl_r) ? T(-1) : T(1);
+  const T v = refl_l ? T(2) * xlo - x : (refl_r ? T(2) * (xlo + W) - x : x);
+  T sa, sb;
+  const Site<T> s = scan_bins<T, MT, false>(a, A.m, v, xlo, W, ylo, H, sa, sb);
+  const bool tail_l = (A.el == NF_EXTRAP_LINEAR) && !(xlo < v);
+  const bool tail_r = (A.er == NF_EXTRAP_LINEAR) && (s.xe < v);
+  const bool tail = tail_l || tail_r;
+  T sg0, sg1;
+  const T d0 = softplus2(s.c0, &sg0), d1 = softplus2(s.c1, &sg1);
+  const T ibw = T(1) / s.bw;
+  const T sl = s.bh * ibw;
+  const T curv = d0 + d1 - T(2) * sl;
+  const T th = (v - s.x0) * ibw;
+  const T om = T(1) - th;
+  const T t1 = th * om;
+  const T den = sl + curv * t1, iden = T(1) / den;
+  const T num = sl * th * th + d0 * t1;
+  const T P = d1 * th * th + T(2) * sl * t1 + d0 * om * om;
+  const T iP = T(1) / P;
+  T g = sl * sl * P * iden * iden;
+  g = tail_l ? d0 : (tail_r ? d1 : g);
+  // dL/dtheta, L = log g (0 on the linear tails)
+  const T Pp = T(2) * (d1 * th + sl * (T(1) - T(2) * th) - d0 * om);
+  const T Lth = tail ? T(0) : (Pp * iP - T(2) * curv * (T(1) - T(2) * th) * iden);
+  // cotangents (gy on the value of the forward map in the actual frame, gl on log g)
+  T gy, gl, grad_in;
+  if (!INV) {
+    gy = gout; gl = glog;
+    grad_in = gy * g + gl * sgn * Lth * ibw;
+  } else {
+    // inverse outputs (x, -L):  dx = (dy - f_p dp)/g ,  d(-L) = -(L_x dx + L_p dp)
+    // => cotangent of y: A1 = (gout - glog L_x)/g ; of p: -A1 f_p - glog L_p
+    const T Lx = sgn * Lth * ibw;
+    const T A1 = (gout - glog * Lx) / g;
+    grad_in = A1;
+    gy = -A1; gl = -glog;
+  }
+  const T gyF = sgn * gy;   // cotangent on F's value in the unreflected frame
+  T d0b, d1b, x0b, wb, y0b, hb;
+  if (tail) {
+    d0b = tail_l ? gyF * (v - xlo) + gl / d0 : T(0);
+    d1b = tail_r ? gyF * (v - s.xe) + gl / d1 : T(0);
+    x0b = wb = y0b = hb = T(0);
+  } else {
+    const T thb = gyF * g * s.bw + gl * Lth;
+    const T i2 = iden * iden;
+    const T slb = gyF * s.bh * (th * th * den - num * (T(1) - T(2) * t1)) * i2 +
+                  gl * (T(2) / sl + T(2) * t1 * iP - T(2) * (T(1) - T(2) * t1) * iden);
+    d0b = gyF * s.bh * t1 * (den - num) * i2 + gl * (om * om * iP - T(2) * t1 * iden);
+    d1b = -gyF * s.bh * num * t1 * i2 + gl * (th * th * iP - T(2) * t1 * iden);
+    hb = gyF * num * iden + slb * ibw;
+    y0b = gyF;
+    x0b = -thb * ibw;
+    wb = -(thb * th + slb * sl) * ibw;
+  }
+  // back through softmax / cumsum (a[] holds the softmax numerators)
+  const T Sx = x0b * (s.x0 - xlo) + wb * s.bw;
+  const T Sy = y0b * (s.y0 - ylo) + hb * s.bh;
+  const T isa = T(1) / sa, isb = T(1) / sb;
+  const T gc0 = d0b * sg0, gc1 = d1b * sg1;
+#pragma unroll
+  for (int k = 0; k < nb; ++k) {
+    const T lead_x = (k < s.j) ? x0b : ((k == s.j) ? wb : T(0));
+    const T lead_y = (k < s.j) ? y0b : ((k == s.j) ? hb : T(0));
+    a[k] = a[k] * isa * (W * lead_x - Sx);
+    a[nb + k] = a[nb + k] * isb * (H * lead_y - Sy);
+  }
+#pragma unroll
+  for (int k = 0; k < m; ++k) a[2 * nb + k] = (k == s.j) ? gc0 : ((k == s.j + 1) ? gc1 : T(0));
+  return grad_in;
+}
+
+// ------------------------------------------------------------------ kernels
+// Unit -> (site, parameter column).  PAIR: unit h covers sites 2h, 2h+1 and the
+// active one is read from the mask; FULL: unit = site.
+template <typename T, int MT, int MODE, bool PAIR>
+__global__ __launch_bounds__(kBlock) void rqs_kernel(RqsArgs A) {
+  constexpr int C = MT > 0 ? 3 * MT - 2 : 1;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  __shared__ double red[kBlock / kWave];
+  const int b = blockIdx.y;
+  const int C_rt = 3 * A.m - 2;
+  const T *__restrict__ xin = static_cast<const T *>(A.x) + int64_t(b) * A.x_bs;
+  const T *__restrict__ par = static_cast<const T *>(A.params) + int64_t(b) * A.p_bs;
+  T *__restrict__ yout = static_cast<T *>(A.y) + int64_t(b) * A.y_bs;
+  double acc = 0.0;
+  const int64_t base = int64_t(blockIdx.x) * kBlock * A.iters + threadIdx.x;
+  for (int it = 0; it < A.iters; ++it) {
+    const int64_t u = base + int64_t(it) * kBlock;
+    if (u >= A.units) break;
+    T v, val = T(0), logd = T(0);
+    bool active;
+    int off = 0;
+    if (PAIR) {
+      const uint16_t mk = reinterpret_cast<const uint16_t *>(A.mask)[u];
+      off = (mk & 0xff) ? 0 : 1;
+      active = true;
+      const typename Pair2<T>::type xv = reinterpret_cast<const typename Pair2<T>::type *>(xin)[u];
+      v = off ? xv.y : xv.x;
+    } else {
+      active = A.mask[u] != 0;
+      v = xin[u];
+    }
+    if (active) {
+      if constexpr (MT > 0) {
+        RegCol<T, C> a;
+#pragma unroll
+        for (int c = 0; c < C; ++c) a[c] = par[int64_t(c) * A.Vp + u];
+        rqs_site<T, MT, MODE == kInv>(a, A, v, val, logd);
+      } else {
+        LdsCol<T> a{reinterpret_cast<T *>(smem_raw) + threadIdx.x};
+        for (int c = 0; c < C_rt; ++c) a[c] = par[int64_t(c) * A.Vp + u];
+        rqs_site<T, 0, MODE == kInv>(a, A, v, val, logd);
+      }
+    }
+    if (PAIR) {
+      // write the pair: transformed value at the active site, 0 at the frozen one
+      typename Pair2<T>::type o;
+      o.x = off ? T(0) : val;
+      o.y = off ? val : T(0);
+      reinterpret_cast<typename Pair2<T>::type *>(yout)[u] = o;
+    } else {
+      yout[u] = val;
+    }
+    acc += double(logd);
+  }
+  const double tot = block_sum(acc, red);
+  if (threadIdx.x == 0) A.partial[int64_t(b) * gridDim.x + blockIdx.x] = tot;
+}
+
+template <typename T, int MT, int MODE, bool PAIR>
+__global__ __launch_bounds__(kBlock) void rqs_vjp_kernel(RqsArgs A) {
+  constexpr int C = MT > 0 ? 3 * MT - 2 : 1;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int b = blockIdx.y;
+  const int C_rt = 3 * A.m - 2;
+  const T *__restrict__ xin = static_cast<const T *>(A.x) + int64_t(b) * A.x_bs;
+  const T *__restrict__ par = static_cast<const T *>(A.params) + int64_t(b) * A.p_bs;
+  const T *__restrict__ gout = static_cast<const T *>(A.grad_out) + int64_t(b) * A.y_bs;
+  T *__restrict__ gin = static_cast<T *>(A.grad_in) + int64_t(b) * A.x_bs;
+  T *__restrict__ gpar = static_cast<T *>(A.grad_params) + int64_t(b) * A.p_bs;
+  const T glog = static_cast<const T *>(A.grad_logj)[b];
+  const int64_t base = int64_t(blockIdx.x) * kBlock * A.iters + threadIdx.x;
+  for (int it = 0; it < A.iters; ++it) {
+    const int64_t u = base + int64_t(it) * kBlock;
+    if (u >= A.units) break;
+    T v, go, gi = T(0);
+    bool active;
+    int off = 0;
+    if (PAIR) {
+      const uint16_t mk = reinterpret_cast<const uint16_t *>(A.mask)[u];
+      off = (mk & 0xff) ? 0 : 1;
+      active = true;
+      const typename Pair2<T>::type xv = reinterpret_cast<const typename Pair2<T>::type *>(xin)[u];
+      const typename Pair2<T>::type gv = reinterpret_cast<const typename Pair2<T>::type *>(gout)[u];
+      v = off ? xv.y : xv.x;
+      go = off ? gv.y : gv.x;
+    } else {
+      active = A.mask[u] != 0;
+      v = xin[u];
+      go = gout[u];
+    }
+    if constexpr (MT > 0) {
+      RegCol<T, C> a;
+      if (active) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) a[c] = par[int64_t(c) * A.Vp + u];
+        gi = rqs_site_vjp<T, MT, MODE == kInv>(a, A, v, go, glog);
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) a[c] = T(0);
+      }
+#pragma unroll
+      for (int c = 0; c < C; ++c) gpar[int64_t(c) * A.Vp + u] = a[c];
+    } else {
+      LdsCol<T> a{reinterpret_cast<T *>(smem_raw) + threadIdx.x};
+      if (active) {
+        for (int c = 0; c < C_rt; ++c) a[c] = par[int64_t(c) * A.Vp + u];
+        gi = rqs_site_vjp<T, 0, MODE == kInv>(a, A, v, go, glog);
+        for (int c = 0; c < C_rt; ++c) gpar[int64_t(c) * A.Vp + u] = a[c];
+      } else {
+        for (int c = 0; c < C_rt; ++c) gpar[int64_t(c) * A.Vp + u] = T(0);
+      }
+    }
+    if (PAIR) {
+      typename Pair2<T>::type o;
+      o.x = off ? T(0) : gi;
+      o.y = off ? gi : T(0);
+      reinterpret_cast<typename Pair2<T>::type *>(gin)[u] = o;
+    } else {
+      gin[u] = gi;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ launchers
+static int fill_args(RqsArgs &A, int64_t B, int64_t V, const nf_rqs_opts *o, const nf_strides *st,
+                     const uint8_t *mask) {
+  NF_REQUIRE(o != nullptr, "nf_rqs: opts is NULL");
+  NF_REQUIRE(mask != nullptr, "nf_rqs: mask is NULL");
+  NF_REQUIRE(B >= 0 && V >= 0, "nf_rqs: negative size");
+  NF_REQUIRE(B <= 65535, "nf_rqs: batch %lld > 65535 (split the batch)", (long long)B);
+  NF_REQUIRE(o->m >= 2, "nf_rqs: knots_len m=%d < 2", o->m);
+  NF_REQUIRE(o->fixed_knots_x == nullptr && o->fixed_knots_y == nullptr,
+             "nf_rqs: fixed knots_x / knots_y are not supported by this build");
+  NF_REQUIRE(o->xhi > o->xlo && o->yhi > o->ylo, "nf_rqs: empty xlim/ylim");
+  for (int e : {o->extrap_left, o->extrap_right})
+    NF_REQUIRE(e == NF_EXTRAP_NONE || e == NF_EXTRAP_LINEAR || e == NF_EXTRAP_ANTI,
+               "nf_rqs: unsupported extrapolation code %d", e);
+  NF_REQUIRE(o->layout == NF_LAYOUT_FULL || o->layout == NF_LAYOUT_PAIR, "nf_rqs: bad layout");
+  if (o->layout == NF_LAYOUT_PAIR) {
+    NF_REQUIRE(V % 2 == 0, "nf_rqs: pair layout needs even V");
+    NF_REQUIRE(!st || (st->x_batch % 2 == 0 && st->y_batch % 2 == 0), "nf_rqs: pair layout needs even batch strides");
+  }
+  const int C = 3 * o->m - 2;
+  A.mask = mask;
+  A.V = V;
+  A.Vp = o->layout == NF_LAYOUT_PAIR ? V / 2 : V;
+  A.units = A.Vp;
+  A.x_bs = (st && st->x_batch) ? st->x_batch : V;
+  A.y_bs = (st && st->y_batch) ? st->y_batch : V;
+  A.p_bs = (st && st->params_batch) ? st->params_batch : int64_t(C) * A.Vp;
+  A.xlo = o->xlo; A.xhi = o->xhi; A.ylo = o->ylo; A.yhi = o->yhi;
+  A.m = o->m; A.el = o->extrap_left; A.er = o->extrap_right; A.layout = o->layout;
+  return NF_OK;
+}
+
+// knots_len values with a register-resident specialisation; everything else takes
+// the LDS-column kernel (any m that fits 64 KiB of LDS per workgroup).
+#define NF_STATIC_M(X) X(4) X(8) X(16)
+
+template <typename T, int MODE, bool VJP>
+static int dispatch(const RqsArgs &A, dim3 grid, hipStream_t stream) {
+  const bool pair = A.layout == NF_LAYOUT_PAIR;
+#define NF_CASE(MV)                                                                         \
+  if (A.m == MV) {                                                                          \
+    if (VJP) {                                                                              \
+      if (pair) hipLaunchKernelGGL((rqs_vjp_kernel<T, MV, MODE, true>), grid, dim3(kBlock), 0, stream, A);  \
+      else hipLaunchKernelGGL((rqs_vjp_kernel<T, MV, MODE, false>), grid, dim3(kBlock), 0, stream, A);      \
+    } else {                                                                                \
+      if (pair) hipLaunchKernelGGL((rqs_kernel<T, MV, MODE, true>), grid, dim3(kBlock), 0, stream, A);      \
+      else hipLaunchKernelGGL((rqs_kernel<T, MV, MODE, false>), grid, dim3(kBlock), 0, stream, A);          \
+    }                                                                                       \
+    return check_launch("rqs kernel");                                                      \
+  }
+  NF_STATIC_M(NF_CASE)
+#undef NF_CASE
+  const size_t lds = size_t(3 * A.m - 2) * kBlock * sizeof(T);
+  NF_REQUIRE(lds <= 64 * 1024, "nf_rqs: knots_len m=%d needs %zu B of LDS per workgroup (> 64 KiB)",
+             A.m, lds);
+  if (VJP) {
+    if (pair) hipLaunchKernelGGL((rqs_vjp_kernel<T, 0, MODE, true>), grid, dim3(kBlock), lds, stream, A);
+    else hipLaunchKernelGGL((rqs_vjp_kernel<T, 0, MODE, false>), grid, dim3(kBlock), lds, stream, A);
+  } else {
+    if (pair) hipLaunchKernelGGL((rqs_kernel<T, 0, MODE, true>), grid, dim3(kBlock), lds, stream, A);
+    else hipLaunchKernelGGL((rqs_kernel<T, 0, MODE, false>), grid, dim3(kBlock), lds, stream, A);
+  }
+  return check_launch("rqs kernel (lds)");
+}
+
+template <typename T, int MODE>
+static int run_map(const void *in, const void *params, const uint8_t *mask, const void *log0, void *out,
+                   void *logj, int64_t B, int64_t V, const nf_rqs_opts *o, const nf_strides *st,
+                   void *ws, size_t ws_bytes, hipStream_t stream) {
+  RqsArgs A{};
+  int rc = fill_args(A, B, V, o, st, mask);
+  if (rc) return rc;
+  NF_REQUIRE(in && params && out && logj, "nf_rqs: NULL tensor pointer");
+  if (B == 0) return NF_OK;
+  const Tiling t = make_tiling(A.units, B);
+  NF_REQUIRE(t.blocks_x <= kMaxBlocksX, "nf_rqs: lattice too large for one launch");
+  const size_t need = size_t(B) * size_t(t.blocks_x > 0 ? t.blocks_x : 1) * sizeof(double);
+  if (ws == nullptr || ws_bytes < need) {
+    set_error("nf_rqs: workspace %zu B < %zu B needed", ws_bytes, need);
+    return NF_EWORKSPACE;
+  }
+  A.x = in; A.params = params; A.y = out; A.partial = static_cast<double *>(ws);
+  A.iters = t.iters;
+  if (t.blocks_x > 0) {
+    rc = dispatch<T, MODE, false>(A, dim3(unsigned(t.blocks_x), unsigned(B)), stream);
+    if (rc) return rc;
+  }
+  return launch_finalize<T>(A.partial, t.blocks_x, log0, logj, B, stream);
+}
+
+template <typename T, int MODE>
+static int run_vjp(const void *x, const void *params, const uint8_t *mask, const void *grad_out,
+                   const void *grad_logj, void *grad_in, void *grad_params, int64_t B, int64_t V,
+                   const nf_rqs_opts *o, const nf_strides *st, hipStream_t stream) {
+  RqsArgs A{};
+  int rc = fill_args(A, B, V, o, st, mask);
+  if (rc) return rc;
+  NF_REQUIRE(x && params && grad_out && grad_logj && grad_in && grad_params, "nf_rqs_vjp: NULL tensor pointer");
+  if (B == 0 || A.units == 0) return NF_OK;
+  const Tiling t = make_tiling(A.units, B);
+  A.x = x; A.params = params; A.grad_out = grad_out; A.grad_logj = grad_logj;
+  A.grad_in = grad_in; A.grad_params = grad_params; A.iters = t.iters;
+  return dispatch<T, MODE, true>(A, dim3(unsigned(t.blocks_x), unsigned(B)), stream);
+}
+
+}  // namespace nf
+
+using namespace nf;
+
+extern "C" int nf_rqs_fwd(const void *x, const void *params, const uint8_t *mask, const void *log0,
+                          void *y, void *logj, int64_t B, int64_t V, const nf_rqs_opts *opts,
+                          const nf_strides *strides, void *workspace, size_t workspace_bytes,
+                          int dtype, void *stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == NF_F32) return run_map<float, kFwd>(x, params, mask, log0, y, logj, B, V, opts, strides, workspace, workspace_bytes, s);
+  if (dtype == NF_F64) return run_map<double, kFwd>(x, params, mask, log0, y, logj, B, V, opts, strides, workspace, workspace_bytes, s);
+  set_error("nf_rqs_fwd: unsupported dtype %d", dtype);
+  return NF_EINVAL;
+}
+
+extern "C" int nf_rqs_inv(const void *y, const void *params, const uint8_t *mask, const void *log0,
+                          void *x, void *logj, int64_t B, int64_t V, const nf_rqs_opts *opts,
+                          const nf_strides *strides, void *workspace, size_t workspace_bytes,
+                          int dtype, void *stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == NF_F32) return run_map<float, kInv>(y, params, mask, log0, x, logj, B, V, opts, strides, workspace, workspace_bytes, s);
+  if (dtype == NF_F64) return run_map<double, kInv>(y, params, mask, log0, x, logj, B, V, opts, strides, workspace, workspace_bytes, s);
+  set_error("nf_rqs_inv: unsupported dtype %d", dtype);
+  return NF_EINVAL;
+}
+
+extern "C" int nf_rqs_fwd_vjp(const void *x, const void *params, const uint8_t *mask,
+                              const void *grad_out, const void *grad_logj, void *grad_in,
+                              void *grad_params, int64_t B, int64_t V, const nf_rqs_opts *opts,
+                              const nf_strides *strides, int dtype, void *stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == NF_F32) return run_vjp<float, kFwd>(x, params, mask, grad_out, grad_logj, grad_in, grad_params, B, V, opts, strides, s);
+  if (dtype == NF_F64) return run_vjp<double, kFwd>(x, params, mask, grad_out, grad_logj, grad_in, grad_params, B, V, opts, strides, s);
+  set_error("nf_rqs_fwd_vjp: unsupported dtype %d", dtype);
+  return NF_EINVAL;
+}
+
+extern "C" int nf_rqs_inv_vjp(const void *x, const void *params, const uint8_t *mask,
+                              const void *grad_out, const void *grad_logj, void *grad_in,
+                              void *grad_params, int64_t B, int64_t V, const nf_rqs_opts *opts,
+                              const nf_strides *strides, int dtype, void *stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == NF_F32) return run_vjp<float, kInv>(x, params, mask, grad_out, grad_logj, grad_in, grad_params, B, V, opts, strides, s);
+  if (dtype == NF_F64) return run_vjp<double, kInv>(x, params, mask, grad_out, grad_logj, grad_in, grad_params, B, V, opts, strides, s);
+  set_error("nf_rqs_inv_vjp: unsupported dtype %d", dtype);
+  return NF_EINVAL;
+}

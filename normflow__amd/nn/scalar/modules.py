@@ -1,0 +1,200 @@
+"""Parameter-producing networks (reference: src/nn/scalar/modules.py): ConvAct,
+LinearAct, SplineNet.  These are the dense contractions of the flow."""
+import copy
+import math
+
+import torch
+
+from .convNd import Conv4d
+from ... import _hip
+
+LN2 = math.log(2.0)
+
+
+class Abs(torch.nn.Module):
+    def forward(self, x):
+        return torch.abs(x)
+
+
+class AvgNeighborPool(torch.nn.Module):
+    """Mean of the 2d nearest neighbours (periodic)."""
+
+    def forward(self, x):
+        dims = range(1, x.ndim)
+        return sum(torch.roll(x, s, d) for d in dims for s in (1, -1)) / (2 * len(dims))
+
+
+ACTIVATIONS = torch.nn.ModuleDict({
+    'tanh': torch.nn.Tanh(), 'relu': torch.nn.ReLU(), 'leaky_relu': torch.nn.LeakyReLU(),
+    'softplus': torch.nn.Softplus(), 'avg_neighbor_pool': AvgNeighborPool(), 'abs': Abs(),
+    'expit': torch.nn.Sigmoid(), 'none': torch.nn.Identity(),
+})
+
+
+class PlusBias(torch.nn.Module):
+    def __init__(self, out_features):
+        super().__init__()
+        self.out_features = out_features
+        self.bias = torch.nn.Parameter(torch.randn(out_features))
+
+    def forward(self, x):
+        return x + self.bias
+
+
+class ConvAct(torch.nn.Sequential):
+    """A stack of circular 'same' convolutions with activations, lattice dimension 1-4
+    (modules.py:68-154).  `acts` has len(hidden_sizes)+1 entries (None = no activation).
+    Input (B, C_in, *L) -> output (B, C_out, *L)."""
+
+    Conv = {1: torch.nn.Conv1d, 2: torch.nn.Conv2d, 3: torch.nn.Conv3d, 4: Conv4d}
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int, conv_dim: int = 2,
+                 hidden_sizes=[], acts=[None], pre_act=None, **extra_kwargs):
+        sizes = [in_channels, *hidden_sizes, out_channels]
+        assert len(acts) == len(hidden_sizes) + 1
+        conv_kwargs = dict(padding='same', padding_mode='circular')
+        conv_kwargs.update(extra_kwargs)
+        layers = [] if pre_act is None else [ACTIVATIONS[pre_act]]
+        for i, act in enumerate(acts):
+            layers.append(self.Conv[conv_dim](sizes[i], sizes[i + 1], kernel_size, **conv_kwargs))
+            if act is not None:
+                layers.append(ACTIVATIONS[act])
+        super().__init__(*layers)
+        self.conv_kwargs = dict(conv_kwargs, in_channels=in_channels, out_channels=out_channels,
+                                kernel_size=kernel_size, conv_dim=conv_dim, hidden_sizes=hidden_sizes,
+                                acts=acts, pre_act=pre_act)
+
+    def set_param2zero(self):
+        for p in self.parameters():
+            torch.nn.init.zeros_(p)
+
+    def transfer(self, scale_factor=1, **extra):
+        if scale_factor != 1:
+            raise NotImplementedError("kernel rescaling on transfer is not supported")
+        return copy.deepcopy(self)
+
+
+class LinearAct(torch.nn.Sequential):
+    """A stack of Linear layers with activations acting on `features_axis`
+    (modules.py:197-273)."""
+
+    def __init__(self, in_features: int, out_features: int, hidden_sizes=[], acts=[None], pre_act=None,
+                 final_bias=False, features_axis=-1, **linear_kwargs):
+        sizes = [in_features, *hidden_sizes, out_features]
+        assert len(acts) == len(hidden_sizes) + 1
+        layers = [] if pre_act is None else [ACTIVATIONS[pre_act]]
+        for i, act in enumerate(acts):
+            layers.append(torch.nn.Linear(sizes[i], sizes[i + 1], **linear_kwargs))
+            if act is not None:
+                layers.append(ACTIVATIONS[act])
+        if final_bias:
+            layers.append(PlusBias(out_features))
+        super().__init__(*layers)
+        self.linear_kwargs = dict(linear_kwargs, in_features=in_features, out_features=out_features,
+                                  hidden_sizes=hidden_sizes, acts=acts, pre_act=pre_act,
+                                  final_bias=final_bias, features_axis=features_axis)
+
+    def forward(self, x):
+        ax = self.linear_kwargs['features_axis']
+        if ax == -1:
+            return super().forward(x)
+        return torch.movedim(super().forward(torch.movedim(x, ax, -1)), -1, ax)
+
+    def set_param2zero(self):
+        for p in self.parameters():
+            torch.nn.init.zeros_(p)
+
+
+def softplus_ln2(t):
+    """log2(1 + 2^t): equals 1 at 0 (modules.py:315)."""
+    return torch.nn.functional.softplus(t, beta=LN2, threshold=20.0)
+
+
+class SplineNet(torch.nn.Module):
+    """ONE learned rational-quadratic spline shared by every element of the input
+    (modules.py:276-391, spline_shape=[] only -- the reference's class-level
+    Softmax(dim=0) makes other shapes ill-defined).
+
+    Parameters (all zero-initialised => identity map): weights_x, weights_y (m-1 logits
+    each, softmax -> bin widths / heights), weights_d (m logits, softplus(beta=ln2) ->
+    knot derivatives; absent when smooth=True: derivatives from neighbouring slopes,
+    spline.py:126-152).
+    """
+
+    def __init__(self, knots_len, xlim=(0, 1), ylim=(0, 1), knots_x=None, knots_y=None, knots_d=None,
+                 spline_shape=[], knots_axis=-1, smooth=False, Spline=None, label='spline',
+                 **spline_kwargs):
+        super().__init__()
+        if len(spline_shape) > 0:
+            raise NotImplementedError("only a single shared spline (spline_shape=[]) is supported")
+        need_len = knots_x is None or knots_y is None or knots_d is None
+        assert not (need_len and knots_len < 2), "oops: knots_len < 2 for splines"
+        self.label = label
+        self.knots_len = knots_len
+        self.knots_x, self.knots_y, self.knots_d = knots_x, knots_y, knots_d
+        self.spline_shape, self.knots_axis = spline_shape, knots_axis
+        self.spline_kwargs = spline_kwargs
+        self.smooth = smooth
+        zeros = lambda n: torch.nn.Parameter(torch.zeros(n))
+        if knots_x is None:
+            self.xlim, self.xwidth = xlim, xlim[1] - xlim[0]
+            self.weights_x = zeros(knots_len - 1)
+        if knots_y is None:
+            self.ylim, self.ywidth = ylim, ylim[1] - ylim[0]
+            self.weights_y = zeros(knots_len - 1)
+        if knots_d is None:
+            self.weights_d = None if smooth else zeros(knots_len)
+
+    # O(m) host-side (device tensors, differentiable) knot construction; the O(B*V)
+    # field pass is the HIP kernel.
+    def knots(self):
+        """(3, K) tensor of boundary-augmented knots x | y | d."""
+        def coords(w, lo, width):
+            frac = torch.cumsum(torch.softmax(w, dim=0), dim=0)
+            return torch.cat((frac.new_zeros(1), frac)) * width + lo
+
+        kx = self.knots_x if self.knots_x is not None else coords(self.weights_x, self.xlim[0], self.xwidth)
+        ky = self.knots_y if self.knots_y is not None else coords(self.weights_y, self.ylim[0], self.ywidth)
+        if self.knots_d is not None:
+            kd = self.knots_d
+        elif self.weights_d is not None:
+            kd = softplus_ln2(self.weights_d)
+        else:
+            slope = (ky[1:] - ky[:-1]) / (kx[1:] - kx[:-1])
+            kd = torch.cat((slope[:1], 0.5 * (slope[1:] + slope[:-1]), slope[-1:]))
+        extrap = self.spline_kwargs.get('extrap', {}) or {}
+        return torch.stack(_augment(kx, ky, kd, extrap.get('left'), extrap.get('right')))
+
+    def _field(self, x, inverse, log0=None):
+        v = x.reshape(1, -1) if x.dim() < 2 else x.reshape(x.shape[0], -1)
+        val, lj = _hip.DistConvFn.apply(v, self.knots(), log0, _hip.STAGE_SPLINE, inverse)
+        return val.reshape(x.shape), lj
+
+    def forward(self, x):
+        return self._field(x, False)[0]
+
+    def backward(self, x):
+        return self._field(x, True)[0]
+
+
+def _augment(kx, ky, kd, left, right):
+    """Boundary knots of a 1-D knot set (spline.py:458-532): 'linear' adds a tangent-line
+    knot one unit outside; 'anti' point-mirrors all other knots through the end knot
+    (after any linear knot on the opposite side has been added)."""
+    anti = ('anti', 'anti-periodic')
+    for side in (left, right):
+        if side not in (None, 'linear') + anti:
+            raise NotImplementedError(f"extrapolation {side!r} is not supported")
+    if left == 'linear':
+        kx, ky, kd = (torch.cat((kx[:1] - 1, kx)), torch.cat((ky[:1] - kd[:1], ky)), torch.cat((kd[:1], kd)))
+    if right == 'linear':
+        kx, ky, kd = (torch.cat((kx, kx[-1:] + 1)), torch.cat((ky, ky[-1:] + kd[-1:])), torch.cat((kd, kd[-1:])))
+    if (left == 'linear' or right == 'linear') and (left is None or right is None):
+        return kx, ky, kd
+    lx = ly = ld = rx = ry = rd = None
+    if left in anti:
+        lx, ly, ld = 2 * kx[0] - kx[1:].flip(0), 2 * ky[0] - ky[1:].flip(0), kd[1:].flip(0)
+    if right in anti:
+        rx, ry, rd = 2 * kx[-1] - kx[:-1].flip(0), 2 * ky[-1] - ky[:-1].flip(0), kd[:-1].flip(0)
+    join = lambda l, c, r: torch.cat([t for t in (l, c, r) if t is not None])
+    return join(lx, kx, rx), join(ly, ky, ry), join(ld, kd, rd)

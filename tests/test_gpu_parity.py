@@ -1,0 +1,403 @@
+"""GPU parity tests (pytest -m gpu): the HIP path, called through the C ABI
+(libnormflow_hip.so via normflow__amd._hip), against
+  * the golden vectors produced by the reference itself (tests/golden/*.npz), and
+  * the CPU oracle on the same seeded inputs,
+plus size-independent properties at BASELINE.json's full sizes.
+
+Tolerances (north_star: "within 1e-5 relative fp32 tolerance"):
+  fp64 kernels : 1e-9  relative (only formula re-association separates them from the fp64 reference)
+  fp32 kernels : 1e-5  relative on the transformed field and on log|J|, at the KERNEL boundary
+                 (same logits in); gradients 2e-4.  At the MODULE boundary (fp32 conv in
+                 front) the bound is 2e-4: the reference's own fp32-vs-fp64 floor there is
+                 6e-5, set by the conv's rounding, not the kernels.
+relative = max|a-b| / max(1, max|b|).
+"""
+import numpy as np
+import pytest
+import torch
+
+import normflow__amd  # noqa: F401
+from normflow__amd import _hip
+from normflow__amd.mask import EvenOddMask
+from normflow__amd.nn import (ConvAct, AffineCoupling_, RQSplineCoupling_, ShiftCoupling_,
+                              MultiRQSplineCoupling_, DistConvertor_, ModuleList_)
+from oracle import nf_oracle as O
+from test_oracle_golden import ATOM_OPTS, atom_cases, dc_cases
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0) if torch.cuda.is_available() else None
+TOL = {torch.float64: dict(val=1e-9, grad=1e-8), torch.float32: dict(val=1e-5, grad=2e-4)}
+
+
+def T(a, dtype=torch.float64, dev=None):
+    return torch.from_numpy(np.asarray(a)).to(device=dev or DEV, dtype=dtype)
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    if b.numel() == 0:
+        return 0.0
+    return float((a - b).abs().max()) / max(1.0, float(b.abs().max()))
+
+
+def compact(t, act):
+    """(B, C, V) full-lattice tensor -> (B, C, V/2): the active site's column of every pair."""
+    B, C, V = t.shape
+    pick = act.reshape(-1, 2)[:, 0].bool()             # True: site 2h is the active one
+    pairs = t.reshape(B, C, V // 2, 2)
+    return torch.where(pick, pairs[..., 0], pairs[..., 1]).contiguous()
+
+
+def uncompact(t, act):
+    B, C, Vh = t.shape
+    pick = act.reshape(-1, 2)[:, 0].bool()
+    z = torch.zeros_like(t)
+    return torch.stack((torch.where(pick, t, z), torch.where(pick, z, t)), dim=-1).reshape(B, C, 2 * Vh)
+
+
+def layouts_for(shape):
+    return ["full", "pair"] if shape[-1] % 2 == 0 else ["full"]
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("tag", atom_cases())
+def test_atoms_against_reference_goldens(golden, tag, dtype):
+    z = golden("atoms")
+    kind = tag.split("/")[0]
+    if kind == "rqs_fixedx":
+        pytest.skip("fixed knots_x: not supported by the kernels yet (raises NotImplementedError)")
+    tol = TOL[dtype]
+    shape, parity = tuple(int(v) for v in z[f"{tag}/shape"]), int(z[f"{tag}/parity"])
+    act = O.channel_mask(shape, parity).to(torch.uint8).reshape(-1).to(DEV)
+    g = lambda k: T(z[f"{tag}/{k}"], dtype)
+    B = g("x_active").shape[0]
+    for layout in layouts_for(shape):
+        lay = _hip.LAYOUT_PAIR if layout == "pair" else _hip.LAYOUT_FULL
+        x = g("x_active")
+        multi = kind == "multirqs"
+        v = (x.reshape(B, 2, -1) if multi else x.reshape(B, -1)).clone().requires_grad_(True)
+        out_full = g("out").reshape(B, g("out").shape[1], -1)
+        if multi and layout == "pair":
+            continue
+        params = (compact(out_full, act) if layout == "pair" else out_full).clone().requires_grad_(True)
+
+        def apply(inp, inverse, log0):
+            if kind in ("affine", "shift"):
+                return _hip.AffineCouplingFn.apply(inp, params, log0, act, lay, inverse)
+            if multi:
+                o = ATOM_OPTS[kind]
+                opts = [_hip.make_rqs_opts(4, o["xlims"][i], o["ylims"][i], o["extraps"][i], lay) for i in range(2)]
+                return _hip.MultiRQSCouplingFn.apply(inp, params, log0, act, opts, inverse)
+            o = ATOM_OPTS[kind]
+            m = (params.shape[1] + 2) // 3
+            return _hip.RQSCouplingFn.apply(inp, params, log0, act,
+                                            _hip.make_rqs_opts(m, o["xlim"], o["ylim"], o["extrap"], lay), inverse)
+
+        y, logJ = apply(v, False, g("log0"))
+        assert rel(y.reshape(x.shape), g("y")) <= tol["val"], (tag, layout, "y")
+        assert rel(logJ, g("logJ")) <= tol["val"], (tag, layout, "logJ")
+        loss = logJ.mean() + (y ** 2).mean()
+        gv, gp = torch.autograd.grad(loss, (v, params))
+        assert rel(gv.reshape(x.shape), g("grad_x")) <= tol["grad"], (tag, layout, "grad_x")
+        gref = g("grad_out").reshape(out_full.shape)
+        assert rel(gp, compact(gref, act) if layout == "pair" else gref) <= tol["grad"], (tag, layout, "grad_out")
+        # inverse + its VJP (checked against autograd through the CPU oracle)
+        yin = g("y").reshape(v.shape).clone().requires_grad_(True)
+        xh, lrt = apply(yin, True, g("logJ"))
+        # conditioning of the inverse: error in x ~ error in y / g; goldens reach g ~ 1e-3
+        assert rel(xh.reshape(x.shape), g("x_active")) <= 200 * tol["val"], (tag, layout, "xhat")
+        assert rel(lrt, g("log0")) <= 200 * tol["val"], (tag, layout, "logJ_rt")
+        if dtype == torch.float64 and kind not in ("multirqs",):
+            linv = lrt.mean() + (xh ** 2).mean()
+            gy, gp2 = torch.autograd.grad(linv, (yin, params))
+            fn = {"affine": O.affine_coupling_atom, "shift": O.shift_coupling_atom}.get(kind, O.rqs_coupling_atom)
+            yo = T(z[f"{tag}/y"], dev="cpu").clone().requires_grad_(True)
+            oo = T(z[f"{tag}/out"], dev="cpu").clone().requires_grad_(True)
+            opts = ATOM_OPTS.get(kind, {})
+            xo, lo = fn(yo, oo, O.channel_mask(shape, parity), inverse=True, log0=T(z[f"{tag}/logJ"], dev="cpu"), **opts)
+            go_y, go_p = torch.autograd.grad(lo.mean() + (xo ** 2).mean(), (yo, oo), allow_unused=True)
+            go_p = torch.zeros_like(oo) if go_p is None else go_p
+            assert rel(gy.reshape(x.shape), go_y) <= 1e-6, (tag, layout, "inv grad_y")
+            gref2 = go_p.reshape(out_full.shape).to(DEV)
+            assert rel(gp2, compact(gref2, act) if layout == "pair" else gref2) <= 1e-6, (tag, layout, "inv grad_p")
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("tag", dc_cases())
+def test_distconvertor_against_reference_goldens(golden, tag, dtype):
+    z = golden("distconv")
+    tol = TOL[dtype]
+    sym, smooth = "sym1" in tag, "sm1" in tag
+    m = int(tag.split("m")[-1])
+    dc = DistConvertor_(m, symmetric=sym, smooth=smooth)
+    dc.to(device=DEV, dtype=dtype)
+    sp = dc.spline_layer_
+    with torch.no_grad():
+        sp.weights_x.copy_(T(z[f"{tag}/wx"], dtype))
+        sp.weights_y.copy_(T(z[f"{tag}/wy"], dtype))
+        if not smooth:
+            sp.weights_d.copy_(T(z[f"{tag}/wd"], dtype))
+    x = T(z[f"{tag}/x"], dtype).requires_grad_(True)
+    y, logJ = dc(x, T(z[f"{tag}/log0"], dtype))
+    # fp32: expit/logit lose relative accuracy in the tails |x| >~ 7 (1 - u is not representable);
+    # the goldens draw x ~ N(0, 2^2), so a handful of points sit there
+    vt = tol["val"] if dtype == torch.float64 else 2e-4
+    assert rel(y, z[f"{tag}/y"]) <= vt
+    assert rel(logJ, z[f"{tag}/logJ"]) <= vt
+    loss = logJ.mean() + (y ** 2).mean()
+    ps = [sp.weights_x, sp.weights_y] + ([] if smooth else [sp.weights_d])
+    grads = torch.autograd.grad(loss, [x] + ps)
+    gt = tol["grad"] if dtype == torch.float64 else 2e-3
+    for gr, name in zip(grads, ["grad_x", "grad_wx", "grad_wy", "grad_wd"]):
+        assert rel(gr, z[f"{tag}/{name}"]) <= gt, name
+    with torch.no_grad():
+        xh, lrt = dc.backward(T(z[f"{tag}/y"], dtype), T(z[f"{tag}/logJ"], dtype))
+    assert rel(xh, z[f"{tag}/x"]) <= 100 * vt
+    assert rel(lrt, z[f"{tag}/log0"]) <= 100 * vt
+    if dtype == torch.float64:   # VJP of the inverse chain against autograd through the oracle
+        yin = T(z[f"{tag}/y"], dtype).requires_grad_(True)
+        xh, lrt = dc.backward(yin, T(z[f"{tag}/logJ"], dtype))
+        gi = torch.autograd.grad(lrt.mean() + (xh ** 2).mean(), [yin] + ps)
+        c = lambda k: T(z[f"{tag}/{k}"], dev="cpu").clone().requires_grad_(True)
+        yo, wx, wy = c("y"), c("wx"), c("wy")
+        wd = None if smooth else c("wd")
+        xo, lo = O.dist_convertor(yo, wx, wy, wd, symmetric=sym, inverse=True, log0=T(z[f"{tag}/logJ"], dev="cpu"))
+        go = torch.autograd.grad(lo.mean() + (xo ** 2).mean(), [yo, wx, wy] + ([] if smooth else [wd]))
+        for a, b in zip(gi, go):
+            assert rel(a, b) <= 1e-6
+
+
+def _load_block(z, tag, kind, d, shape, dtype):
+    m = 6
+    n_out = 2 if kind == "affine" else 3 * m - 2
+    nets = [ConvAct(1, n_out, 3, conv_dim=d, hidden_sizes=[4, 4], acts=['tanh', 'tanh', None]) for _ in range(3)]
+    mask = EvenOddMask(shape=shape)
+    if kind == "affine":
+        cpl = AffineCoupling_(nets, mask=mask)
+    else:
+        cpl = RQSplineCoupling_(nets, mask=mask, xlim=(-3.0, 3.0), ylim=(-3.0, 3.0),
+                                extrap={'left': 'linear', 'right': 'linear'})
+    sd = {k.split("/param/")[1]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"{tag}/param/")}
+    missing, unexpected = cpl.load_state_dict(sd, strict=False)
+    assert not unexpected and set(missing) == {"mask._mask", "mask._c_mask"}
+    return cpl.to(device=DEV, dtype=dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("kind", ["affine", "rqs"])
+@pytest.mark.parametrize("d", [1, 2, 3, 4])
+def test_coupling_blocks_with_convact_against_goldens(golden, kind, d, dtype):
+    """Module boundary: reference weights in (same state_dict keys), reference y / logJ /
+    grads out."""
+    z = golden("blocks")
+    tag = f"{kind}/d{d}"
+    shape = tuple(int(v) for v in z[f"{tag}/shape"])
+    cpl = _load_block(z, tag, kind, d, shape, dtype)
+    vt, gt = (1e-9, 1e-7) if dtype == torch.float64 else (2e-4, 2e-3)
+    x = T(z[f"{tag}/x"], dtype).requires_grad_(True)
+    y, logJ = cpl(x)
+    assert rel(y, z[f"{tag}/y"]) <= vt
+    assert rel(logJ, z[f"{tag}/logJ"]) <= vt
+    loss = logJ.mean() + (y ** 2).mean()
+    names = [n for n, _ in cpl.named_parameters()]
+    grads = torch.autograd.grad(loss, [x] + [p for _, p in cpl.named_parameters()])
+    assert rel(grads[0], z[f"{tag}/grad_x"]) <= gt
+    for n, gp in zip(names, grads[1:]):
+        assert rel(gp, z[f"{tag}/gparam/{n}"]) <= gt, n
+    with torch.no_grad():
+        xh, lrt = cpl.backward(T(z[f"{tag}/y"], dtype), T(z[f"{tag}/logJ"], dtype))
+    # min g ~ 1e-4 in these random-init nets: the inverse amplifies rounding by 1/g
+    assert rel(xh, z[f"{tag}/x"]) <= (1e-6 if dtype == torch.float64 else 5e-2)
+    assert float(lrt.abs().max()) <= (1e-6 if dtype == torch.float64 else 5e-1)
+
+
+def test_c1_readme_model_against_golden(golden):
+    z = golden("callers")
+    from normflow__amd import Model
+    from normflow__amd.prior import NormalPrior
+    from normflow__amd.action import ScalarPhi4Action
+    for dtype, tol in ((torch.float64, 1e-10), (torch.float32, 1e-5)):
+        net_ = DistConvertor_(knots_len=10, symmetric=True)
+        net_.to(device=DEV, dtype=dtype)
+        sp = net_.spline_layer_
+        with torch.no_grad():
+            sp.weights_x.copy_(T(z["c1/wx"], dtype))
+            sp.weights_y.copy_(T(z["c1/wy"], dtype))
+            sp.weights_d.copy_(T(z["c1/wd"], dtype))
+        prior = NormalPrior(loc=torch.zeros(1, device=DEV, dtype=dtype), scale=torch.ones(1, device=DEV, dtype=dtype))
+        model = Model(net_=net_, prior=prior, action=ScalarPhi4Action(kappa=0, m_sq=-1.2, lambd=0.5))
+        x = T(z["c1/x"], dtype)
+        y, logJ = net_(x)
+        logq = prior.log_prob(x) - logJ
+        logp = -model.action(y)
+        assert rel(y, z["c1/y"]) <= tol and rel(logJ, z["c1/logJ"]) <= tol
+        assert rel(logq, z["c1/logq"]) <= tol and rel(logp, z["c1/logp"]) <= 10 * tol
+        assert abs(model.fit.calc_kl_mean(logq, logp).item() - float(z["c1/loss"])) <= 20 * tol
+        assert rel(model.posterior.log_prob(T(z["c1/y"], dtype)), z["c1/log_prob"]) <= 50 * tol
+
+
+def test_readme_training_reaches_analytic_logz():
+    """End-to-end statistical KAT: 0-dim phi^4, m^2=-1.2, lambda=0.5,
+    log Z = 1.112773; Model.fit() unchanged on the HIP path."""
+    from normflow__amd import Model
+    from normflow__amd.prior import NormalPrior
+    from normflow__amd.action import ScalarPhi4Action
+    torch.manual_seed(11)
+    net_ = DistConvertor_(knots_len=10, symmetric=True)
+    net_.to(device=DEV, dtype=torch.float64)
+    prior = NormalPrior(loc=torch.zeros(1, device=DEV, dtype=torch.float64),
+                        scale=torch.ones(1, device=DEV, dtype=torch.float64))
+    model = Model(net_=net_, prior=prior, action=ScalarPhi4Action(kappa=0, m_sq=-1.2, lambd=0.5))
+    model.fit(n_epochs=300, batch_size=512, hyperparam=dict(lr=0.01, weight_decay=0.0),
+              checkpoint_dict=dict(print_stride=100, print_batch_size=4096))
+    h = model.fit.train_history
+    assert abs(h['logz'][-1][0] - 1.112773) < 0.01
+    assert h['accept_rate'][-1][0] > 0.85
+    assert float(h['ess'][-1]) > 0.9
+
+
+# ------------------------------------------------------------ seeded oracle comparisons
+def _rand_case(shape, B, m, seed, dtype, out_std=0.5, x_std=1.0):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    x = x_std * torch.randn((B,) + shape, generator=g, dtype=torch.float64, device='cpu')
+    out = out_std * torch.randn((B, 3 * m - 2) + shape, generator=g, dtype=torch.float64, device='cpu')
+    return x, out
+
+
+@pytest.mark.parametrize("m", [2, 3, 4, 8, 10, 16, 24])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_rqs_kernel_vs_oracle_all_m(m, dtype):
+    """Register-resident (m = 4, 8, 16) and LDS-column (other m) kernels, both layouts,
+    synthetic inputs of SURVEY 8(d): x ~ N(0,1) (scaled to reach the tails), logits ~ N(0, 0.5^2)."""
+    shape, B = (6, 4, 8), 5
+    tol = TOL[dtype]
+    x, out = _rand_case(shape, B, m, 100 + m, dtype, x_std=3.0)
+    opts = dict(xlim=(-5.0, 5.0), ylim=(-5.0, 5.0), extrap={'left': 'linear', 'right': 'linear'})
+    for parity in (0, 1):
+        am = O.channel_mask(shape, parity)
+        xa = x * am
+        yo, lo = O.rqs_coupling_atom(xa, out, am, **opts)
+        act = am.to(torch.uint8).reshape(-1).to(DEV)
+        for lay in (_hip.LAYOUT_FULL, _hip.LAYOUT_PAIR):
+            full = out.reshape(B, 3 * m - 2, -1).to(DEV, dtype)
+            params = compact(full, act) if lay == _hip.LAYOUT_PAIR else full
+            o = _hip.make_rqs_opts(m, opts["xlim"], opts["ylim"], opts["extrap"], lay)
+            y, lj = _hip.RQSCouplingFn.apply(xa.reshape(B, -1).to(DEV, dtype), params, None, act, o, False)
+            assert rel(y.reshape(x.shape), yo) <= tol["val"]
+            assert rel(lj, lo) <= tol["val"]
+            xb, lb = _hip.RQSCouplingFn.apply(y, params, lj, act, o, True)
+            assert rel(xb.reshape(x.shape), xa) <= 50 * tol["val"]
+            assert float(lb.abs().max()) <= 50 * tol["val"] * max(1.0, float(lo.abs().max()))
+
+
+def test_edge_cases_empty_ragged_extreme():
+    o = _hip.make_rqs_opts(4, (-1, 1), (-1, 1), {'left': 'linear', 'right': 'linear'}, 0)
+    act = torch.ones(7, dtype=torch.uint8, device=DEV)
+    # empty batch
+    y, lj = _hip.RQSCouplingFn.apply(torch.zeros(0, 7, device=DEV), torch.zeros(0, 10, 7, device=DEV), None, act, o, False)
+    assert y.shape == (0, 7) and lj.shape == (0,)
+    # odd V (ragged against the 256-thread tile), all-frozen mask => identity-free zeros, logJ = log0
+    none = torch.zeros(7, dtype=torch.uint8, device=DEV)
+    l0 = torch.arange(3, device=DEV, dtype=torch.float64)
+    y, lj = _hip.RQSCouplingFn.apply(torch.randn(3, 7, device=DEV), torch.randn(3, 10, 7, device=DEV), l0, none, o, False)
+    assert float(y.abs().max()) == 0.0 and torch.equal(lj, l0)
+    # zero logits => identity map inside the limits, log|J| = 0 (softplus_ln2(0) = 1, equal bins)
+    x = torch.linspace(-3, 3, 70, device=DEV).reshape(10, 7)
+    y, lj = _hip.RQSCouplingFn.apply(x, torch.zeros(10, 10, 7, device=DEV), None, act, o, False)
+    assert float((y - x).abs().max()) < 1e-14 and float(lj.abs().max()) < 1e-13
+    # extreme logits: huge derivative logit (softplus threshold branch) and very negative one
+    p = torch.zeros(1, 10, 7, device=DEV)
+    p[:, 6:] = 40.0
+    p[:, 7] = -40.0
+    y, lj = _hip.RQSCouplingFn.apply(torch.zeros(1, 7, device=DEV) + 0.1, p, None, act, o, False)
+    yo, lo = O.rqs_coupling_atom(torch.full((1, 7), 0.1, dtype=torch.float64, device='cpu'), p.cpu(),
+                                 torch.ones(7, dtype=torch.float64, device='cpu'), xlim=(-1, 1), ylim=(-1, 1),
+                                 extrap={'left': 'linear', 'right': 'linear'})
+    assert rel(y, yo) < 1e-9 and rel(lj, lo) < 1e-9
+    # batch larger than one grid's y extent is cut into slabs
+    Bbig = _hip.MAX_B + 5
+    x = torch.randn(Bbig, 2, device=DEV, dtype=torch.float32)
+    p = 0.3 * torch.randn(Bbig, 2, 2, device=DEV, dtype=torch.float32)
+    a2 = torch.ones(2, dtype=torch.uint8, device=DEV)
+    y, lj = _hip.AffineCouplingFn.apply(x, p, None, a2, 0, False)
+    assert rel(y, p[:, 0] + x * torch.exp(-p[:, 1].abs())) < 1e-6 and rel(lj, -p[:, 1].abs().sum(1)) < 1e-6
+    with pytest.raises(TypeError):
+        _hip.RQSCouplingFn.apply(torch.zeros(1, 7, device=DEV, dtype=torch.float16),
+                                 torch.zeros(1, 10, 7, device=DEV, dtype=torch.float16), None, act, o, False)
+
+
+# -------------------------------------------------- BASELINE sizes: size-independent properties
+def _big_properties(shape, B, m, dtype):
+    V = int(np.prod(shape))
+    torch.manual_seed(5)
+    mask = EvenOddMask(shape=shape)
+    act = mask.activity(0).reshape(-1).to(DEV)
+    x = torch.randn(B, V, device=DEV, dtype=dtype)
+    xa = x * act.to(dtype)
+    pc = 0.5 * torch.randn(B, 3 * m - 2, V // 2, device=DEV, dtype=dtype)
+    lim = dict(xlim=(-5.0, 5.0), ylim=(-5.0, 5.0), extrap={'left': 'linear', 'right': 'linear'})
+    op = _hip.make_rqs_opts(m, lim["xlim"], lim["ylim"], lim["extrap"], _hip.LAYOUT_PAIR)
+    of = _hip.make_rqs_opts(m, lim["xlim"], lim["ylim"], lim["extrap"], _hip.LAYOUT_FULL)
+    y, lj = _hip.RQSCouplingFn.apply(xa, pc, None, act, op, False)
+    # (1) frozen sites are exactly zero, active sites finite and monotone-consistent
+    assert float((y * (1 - act.to(dtype))).abs().max()) == 0.0 and bool(torch.isfinite(y).all())
+    # (2) round trip: inverse(forward) = id and the log-Jacobians cancel
+    xb, lb = _hip.RQSCouplingFn.apply(y, pc, lj, act, op, True)
+    scale = max(1.0, float(lj.abs().max()))
+    rt = (1e-10, 1e-9) if dtype == torch.float64 else (2e-4, 2e-5)
+    assert float((xb - xa).abs().max()) <= rt[0] * 50
+    assert float(lb.abs().max()) <= rt[1] * scale * 50
+    # (3) pair layout == full layout (same arithmetic, different addressing)
+    nsub = min(B, 2)
+    yf, ljf = _hip.RQSCouplingFn.apply(xa[:nsub], uncompact(pc[:nsub], act), None, act, of, False)
+    assert rel(yf, y[:nsub]) <= (1e-14 if dtype == torch.float64 else 1e-6)
+    assert rel(ljf, lj[:nsub]) <= (1e-12 if dtype == torch.float64 else 1e-6)
+    # (4) samples are independent: a permuted batch gives the permuted result, bitwise
+    perm = torch.randperm(B, device=DEV)
+    yp, ljp = _hip.RQSCouplingFn.apply(xa[perm], pc[perm], None, act, op, False)
+    assert torch.equal(yp, y[perm]) and torch.equal(ljp, lj[perm])
+    # (5) one sample against the fp64 CPU oracle
+    am = O.channel_mask(shape, 0)
+    yo, lo = O.rqs_coupling_atom(xa[:1].double().cpu().reshape((1,) + shape),
+                                 uncompact(pc[:1], act).double().cpu().reshape((1, 3 * m - 2) + shape), am, **lim)
+    assert rel(y[:1].reshape((1,) + shape), yo) <= TOL[dtype]["val"]
+    assert rel(lj[:1], lo) <= TOL[dtype]["val"]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_config3_full_size_properties(dtype):
+    """BASELINE config 3: 16^3, m=16, batch 1024."""
+    _big_properties((16, 16, 16), 1024, 16, dtype)
+
+
+def test_config4_full_lattice_properties():
+    """BASELINE config 4 lattice (32^4, m=16) at the per-GPU kernel slab that bench.py uses."""
+    _big_properties((32, 32, 32, 32), 8, 16, torch.float32)
+
+
+def test_posterior_sample_and_sanity_on_lattice():
+    """Model.posterior.sample / log_prob / backward_sanitychecker unchanged on a 2-D lattice
+    with mixed blocks (BASELINE config 2 shapes: 16x16, affine)."""
+    from normflow__amd import Model, backward_sanitychecker
+    from normflow__amd.prior import NormalPrior
+    from normflow__amd.action import ScalarPhi4Action
+    torch.manual_seed(3)
+    shape = (16, 16)
+    dt = torch.float64
+    mask = EvenOddMask(shape=shape)
+    mk = lambda c: ConvAct(1, c, 3, conv_dim=2, hidden_sizes=[8, 8], acts=['tanh', 'tanh', None])
+    net_ = ModuleList_([AffineCoupling_([mk(2) for _ in range(4)], mask=mask),
+                        RQSplineCoupling_([mk(22) for _ in range(2)], mask=mask, xlim=(-5, 5), ylim=(-5, 5),
+                                          extrap={'left': 'linear', 'right': 'linear'}),
+                        ShiftCoupling_([mk(1)], mask=mask),
+                        DistConvertor_(8, symmetric=True)])
+    net_.to(device=DEV, dtype=dt)
+    prior = NormalPrior(loc=torch.zeros(shape, device=DEV, dtype=dt), scale=torch.ones(shape, device=DEV, dtype=dt))
+    model = Model(net_=net_, prior=prior, action=ScalarPhi4Action(kappa=0.67, m_sq=-4 * 0.67, lambd=0.5))
+    y, logq, logp = model.posterior.sample__(512)
+    assert y.shape == (512,) + shape and bool(torch.isfinite(logq).all())
+    assert rel(model.posterior.log_prob(y), logq) < 1e-8
+    (x, yy, xh), (lj, l0) = backward_sanitychecker(model, n_samples=5, return_details=True)
+    assert float((x - xh).abs().sum()) < 1e-8 and float(l0.abs().sum()) < 1e-8
+    model.fit(n_epochs=3, batch_size=64, checkpoint_dict=dict(print_stride=1, print_batch_size=64))
+    assert np.isfinite(model.fit.train_history['loss']).all()
