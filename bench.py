@@ -102,7 +102,13 @@ def cpu_baseline(cpl, lattice, m, budget_s):
     """The CPU oracle restatement (plain PyTorch CPU ops, all host threads, fp32) on a bounded
     sample of the same workload: whole coupling layers of the bench network at batch 1."""
     from oracle import nf_oracle as O
-    nthreads = os.cpu_count() or 1
+    # the GPU box gives one GPU's job a 16-CPU share (task statement); more threads than that
+    # only oversubscribes (256 threads ran 10x slower than 8 in the build container)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    nthreads = max(1, min(avail, 16))
     torch.set_num_threads(nthreads)
     nets = []
     for net in cpl.nets:
@@ -125,7 +131,8 @@ def cpu_baseline(cpl, lattice, m, budget_s):
             out = net(parts[1 - p].unsqueeze(1))
             parts[p], log0 = O.rqs_coupling_atom(parts[p], out, masks[p], log0=log0, **opts)
             done += 1
-            if time.time() - t0 > budget_s:
+            spent = time.time() - t0
+            if spent + spent / done > budget_s:     # the next layer would overrun the budget
                 break
     dt = time.time() - t0
     per_cfg = dt / done * len(nets)

@@ -56,8 +56,9 @@ extern "C" int nf_version(void) { return NF_VERSION; }
 extern "C" const char *nf_last_error_string(void) { return nf::g_err; }
 extern "C" size_t nf_workspace_bytes(int64_t B, int64_t V) {
   if (B < 0 || V < 0) return 0;
-  // worst case of make_tiling: one double per 256-unit workgroup per sample, plus
-  // room for the 3K-per-workgroup knot-cotangent partials of nf_distconv_vjp
-  const int64_t blocks = (V + nf::kBlock - 1) / nf::kBlock + 1;
+  // worst case of make_tiling: one double per 64-unit workgroup per sample (the LDS-column
+  // kernel may shrink its workgroup to one wave), plus room for the 3K-per-workgroup
+  // knot-cotangent partials of nf_distconv_vjp
+  const int64_t blocks = (V + nf::kWave - 1) / nf::kWave + 1;
   return size_t(B) * size_t(blocks) * sizeof(double) + (size_t(8) << 20);
 }

@@ -263,7 +263,7 @@ static int run_vjp(const void *v, const void *knots, int K, const void *grad_out
   int blocks = int((n + kBlock - 1) / kBlock);
   if (blocks > kVjpBlocks) blocks = kVjpBlocks;
   if (blocks == 0) {
-    if (n3) hipMemsetAsync(grad_knots, 0, size_t(n3) * sizeof(double), stream);
+    if (n3) (void)hipMemsetAsync(grad_knots, 0, size_t(n3) * sizeof(double), stream);
     return NF_OK;
   }
   const size_t need = size_t(blocks) * size_t(n3 > 0 ? n3 : 1) * sizeof(double);

@@ -81,7 +81,8 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;  // valid in lane 0
 }
 
-// Sum over the workgroup; result valid in thread 0.  `smem` needs kBlock/kWave doubles.
+// Sum over the workgroup (blockDim.x <= kBlock); result valid in thread 0.  `smem` needs
+// kBlock/kWave doubles.
 __device__ __forceinline__ double block_sum(double v, double *smem) {
   v = wave_sum(v);
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
@@ -89,8 +90,8 @@ __device__ __forceinline__ double block_sum(double v, double *smem) {
   __syncthreads();
   double r = 0;
   if (threadIdx.x == 0) {
-#pragma unroll
-    for (int i = 0; i < kBlock / kWave; ++i) r += smem[i];
+    const int nw = (blockDim.x + kWave - 1) / kWave;
+    for (int i = 0; i < nw; ++i) r += smem[i];
   }
   return r;
 }
@@ -107,14 +108,14 @@ struct Tiling {
   int iters;          // units per thread
   int64_t blocks_x;   // workgroups per sample
 };
-inline Tiling make_tiling(int64_t units, int64_t B) {
+inline Tiling make_tiling(int64_t units, int64_t B, int block = kBlock) {
   Tiling t;
   t.units = units;
   // aim for >= ~4 waves of workgroups over 256 CUs before growing the per-thread loop
   int iters = 1;
-  while (iters < 8 && (units / (int64_t(kBlock) * iters * 2)) * B >= 8192) iters *= 2;
+  while (iters < 8 && (units / (int64_t(block) * iters * 2)) * B >= 8192) iters *= 2;
   t.iters = iters;
-  t.blocks_x = (units + int64_t(kBlock) * iters - 1) / (int64_t(kBlock) * iters);
+  t.blocks_x = (units + int64_t(block) * iters - 1) / (int64_t(block) * iters);
   return t;
 }
 

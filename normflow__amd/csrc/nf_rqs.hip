@@ -47,8 +47,9 @@ template <typename T, int C> struct RegCol {   // static m: logits live in VGPRs
   __device__ __forceinline__ T &operator[](int i) { return v[i]; }
 };
 template <typename T> struct LdsCol {          // runtime m: one LDS column per lane
-  T *p;                                        // bank = lane % 32 for every row: conflict-free
-  __device__ __forceinline__ T &operator[](int i) const { return p[i * kBlock]; }
+  T *p;                                        // row stride = blockDim.x (a multiple of 64):
+  int stride;                                  // bank = lane % 32 for every row, conflict-free
+  __device__ __forceinline__ T &operator[](int i) const { return p[i * stride]; }
 };
 
 template <typename T> struct Pair2;   // two adjacent sites as one 8/16-byte access
@@ -251,9 +252,9 @@ __global__ __launch_bounds__(kBlock) void rqs_kernel(RqsArgs A) {
   const T *__restrict__ par = static_cast<const T *>(A.params) + int64_t(b) * A.p_bs;
   T *__restrict__ yout = static_cast<T *>(A.y) + int64_t(b) * A.y_bs;
   double acc = 0.0;
-  const int64_t base = int64_t(blockIdx.x) * kBlock * A.iters + threadIdx.x;
+  const int64_t base = int64_t(blockIdx.x) * blockDim.x * A.iters + threadIdx.x;
   for (int it = 0; it < A.iters; ++it) {
-    const int64_t u = base + int64_t(it) * kBlock;
+    const int64_t u = base + int64_t(it) * blockDim.x;
     if (u >= A.units) break;
     T v, val = T(0), logd = T(0);
     bool active;
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void rqs_kernel(RqsArgs A) {
         for (int c = 0; c < C; ++c) a[c] = par[int64_t(c) * A.Vp + u];
         rqs_site<T, MT, MODE == kInv>(a, A, v, val, logd);
       } else {
-        LdsCol<T> a{reinterpret_cast<T *>(smem_raw) + threadIdx.x};
+        LdsCol<T> a{reinterpret_cast<T *>(smem_raw) + threadIdx.x, int(blockDim.x)};
         for (int c = 0; c < C_rt; ++c) a[c] = par[int64_t(c) * A.Vp + u];
         rqs_site<T, 0, MODE == kInv>(a, A, v, val, logd);
       }
@@ -307,9 +308,9 @@ __global__ __launch_bounds__(kBlock) void rqs_vjp_kernel(RqsArgs A) {
   T *__restrict__ gin = static_cast<T *>(A.grad_in) + int64_t(b) * A.x_bs;
   T *__restrict__ gpar = static_cast<T *>(A.grad_params) + int64_t(b) * A.p_bs;
   const T glog = static_cast<const T *>(A.grad_logj)[b];
-  const int64_t base = int64_t(blockIdx.x) * kBlock * A.iters + threadIdx.x;
+  const int64_t base = int64_t(blockIdx.x) * blockDim.x * A.iters + threadIdx.x;
   for (int it = 0; it < A.iters; ++it) {
-    const int64_t u = base + int64_t(it) * kBlock;
+    const int64_t u = base + int64_t(it) * blockDim.x;
     if (u >= A.units) break;
     T v, go, gi = T(0);
     bool active;
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(kBlock) void rqs_vjp_kernel(RqsArgs A) {
 #pragma unroll
       for (int c = 0; c < C; ++c) gpar[int64_t(c) * A.Vp + u] = a[c];
     } else {
-      LdsCol<T> a{reinterpret_cast<T *>(smem_raw) + threadIdx.x};
+      LdsCol<T> a{reinterpret_cast<T *>(smem_raw) + threadIdx.x, int(blockDim.x)};
       if (active) {
         for (int c = 0; c < C_rt; ++c) a[c] = par[int64_t(c) * A.Vp + u];
         gi = rqs_site_vjp<T, 0, MODE == kInv>(a, A, v, go, glog);
@@ -396,8 +397,26 @@ static int fill_args(RqsArgs &A, int64_t B, int64_t V, const nf_rqs_opts *o, con
 // the LDS-column kernel (any m that fits 64 KiB of LDS per workgroup).
 #define NF_STATIC_M(X) X(4) X(8) X(16)
 
+static bool has_static_kernel(int m) {
+#define NF_IS(MV) if (m == MV) return true;
+  NF_STATIC_M(NF_IS)
+#undef NF_IS
+  return false;
+}
+
+// Workgroup size: 256 for the register kernels; the LDS-column kernel keeps one column of
+// C logits per lane, so it shrinks the workgroup until the tile fits 64 KiB and opts in to
+// the CU's full 160 KiB only for very long splines.  Returns 0 if even 64 lanes do not fit.
+template <typename T> static int pick_block(int m) {
+  if (has_static_kernel(m)) return kBlock;
+  const size_t col = size_t(3 * m - 2) * sizeof(T);
+  int block = kBlock;
+  while (block > kWave && col * block > 64 * 1024) block >>= 1;
+  return col * block <= 160 * 1024 ? block : 0;
+}
+
 template <typename T, int MODE, bool VJP>
-static int dispatch(const RqsArgs &A, dim3 grid, hipStream_t stream) {
+static int dispatch(const RqsArgs &A, dim3 grid, int block, hipStream_t stream) {
   const bool pair = A.layout == NF_LAYOUT_PAIR;
 #define NF_CASE(MV)                                                                         \
   if (A.m == MV) {                                                                          \
@@ -412,16 +431,22 @@ static int dispatch(const RqsArgs &A, dim3 grid, hipStream_t stream) {
   }
   NF_STATIC_M(NF_CASE)
 #undef NF_CASE
-  const size_t lds = size_t(3 * A.m - 2) * kBlock * sizeof(T);
-  NF_REQUIRE(lds <= 64 * 1024, "nf_rqs: knots_len m=%d needs %zu B of LDS per workgroup (> 64 KiB)",
-             A.m, lds);
+  const size_t lds = size_t(3 * A.m - 2) * sizeof(T) * block;
+#define NF_LDS_LAUNCH(KERNEL)                                                                     \
+  do {                                                                                            \
+    if (lds > 64 * 1024)                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL),                          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));            \
+    hipLaunchKernelGGL(KERNEL, grid, dim3(block), lds, stream, A);                               \
+  } while (0)
   if (VJP) {
-    if (pair) hipLaunchKernelGGL((rqs_vjp_kernel<T, 0, MODE, true>), grid, dim3(kBlock), lds, stream, A);
-    else hipLaunchKernelGGL((rqs_vjp_kernel<T, 0, MODE, false>), grid, dim3(kBlock), lds, stream, A);
+    if (pair) NF_LDS_LAUNCH((rqs_vjp_kernel<T, 0, MODE, true>));
+    else NF_LDS_LAUNCH((rqs_vjp_kernel<T, 0, MODE, false>));
   } else {
-    if (pair) hipLaunchKernelGGL((rqs_kernel<T, 0, MODE, true>), grid, dim3(kBlock), lds, stream, A);
-    else hipLaunchKernelGGL((rqs_kernel<T, 0, MODE, false>), grid, dim3(kBlock), lds, stream, A);
+    if (pair) NF_LDS_LAUNCH((rqs_kernel<T, 0, MODE, true>));
+    else NF_LDS_LAUNCH((rqs_kernel<T, 0, MODE, false>));
   }
+#undef NF_LDS_LAUNCH
   return check_launch("rqs kernel (lds)");
 }
 
@@ -434,7 +459,9 @@ static int run_map(const void *in, const void *params, const uint8_t *mask, cons
   if (rc) return rc;
   NF_REQUIRE(in && params && out && logj, "nf_rqs: NULL tensor pointer");
   if (B == 0) return NF_OK;
-  const Tiling t = make_tiling(A.units, B);
+  const int block = pick_block<T>(A.m);
+  NF_REQUIRE(block > 0, "nf_rqs: knots_len m=%d does not fit the 160 KiB of LDS of one CU", A.m);
+  const Tiling t = make_tiling(A.units, B, block);
   NF_REQUIRE(t.blocks_x <= kMaxBlocksX, "nf_rqs: lattice too large for one launch");
   const size_t need = size_t(B) * size_t(t.blocks_x > 0 ? t.blocks_x : 1) * sizeof(double);
   if (ws == nullptr || ws_bytes < need) {
@@ -444,7 +471,7 @@ static int run_map(const void *in, const void *params, const uint8_t *mask, cons
   A.x = in; A.params = params; A.y = out; A.partial = static_cast<double *>(ws);
   A.iters = t.iters;
   if (t.blocks_x > 0) {
-    rc = dispatch<T, MODE, false>(A, dim3(unsigned(t.blocks_x), unsigned(B)), stream);
+    rc = dispatch<T, MODE, false>(A, dim3(unsigned(t.blocks_x), unsigned(B)), block, stream);
     if (rc) return rc;
   }
   return launch_finalize<T>(A.partial, t.blocks_x, log0, logj, B, stream);
@@ -459,10 +486,12 @@ static int run_vjp(const void *x, const void *params, const uint8_t *mask, const
   if (rc) return rc;
   NF_REQUIRE(x && params && grad_out && grad_logj && grad_in && grad_params, "nf_rqs_vjp: NULL tensor pointer");
   if (B == 0 || A.units == 0) return NF_OK;
-  const Tiling t = make_tiling(A.units, B);
+  const int block = pick_block<T>(A.m);
+  NF_REQUIRE(block > 0, "nf_rqs: knots_len m=%d does not fit the 160 KiB of LDS of one CU", A.m);
+  const Tiling t = make_tiling(A.units, B, block);
   A.x = x; A.params = params; A.grad_out = grad_out; A.grad_logj = grad_logj;
   A.grad_in = grad_in; A.grad_params = grad_params; A.iters = t.iters;
-  return dispatch<T, MODE, true>(A, dim3(unsigned(t.blocks_x), unsigned(B)), stream);
+  return dispatch<T, MODE, true>(A, dim3(unsigned(t.blocks_x), unsigned(B)), block, stream);
 }
 
 }  // namespace nf

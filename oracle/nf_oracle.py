@@ -39,11 +39,11 @@ def even_odd_mask(shape, parity=0, dtype=torch.uint8):
     coupling layers k = 0, 2, ... (src/nn/scalar/couplings_.py:56-57).
     """
     shape = tuple(int(l) for l in shape)
-    total = torch.zeros(shape, dtype=torch.int64)
+    total = torch.zeros(shape, dtype=torch.int64, device='cpu')
     for mu, l in enumerate(shape):
         view = [1] * len(shape)
         view[mu] = l
-        total = total + torch.arange(l, dtype=torch.int64).reshape(view)
+        total = total + torch.arange(l, dtype=torch.int64, device='cpu').reshape(view)
     return ((1 - parity + total) % 2).to(dtype)
 
 
@@ -70,7 +70,7 @@ def coords_from_logits(w, lo, width, axis=1):
     frac = torch.cumsum(torch.softmax(w, dim=axis), dim=axis)
     zero_shape = list(w.shape)
     zero_shape[axis] = 1
-    frac = torch.cat((torch.zeros(zero_shape, dtype=w.dtype), frac), dim=axis)
+    frac = torch.cat((w.new_zeros(zero_shape), frac), dim=axis)
     return frac * width + lo
 
 
@@ -210,7 +210,8 @@ def rqs_invert(kx, ky, kd, w, axis=1):
 
     The reference solves a2 th^2 + a1 th + a0 = 0 with th = (-a1 - delta)/(2 a2),
     which cancels catastrophically as a2 -> 0 (linear tails).
-    The oracle uses the algebraically identical, stable form th = 2 a0/(-a1+delta);
+    The oracle uses the algebraically identical, stable forms th = 2 a0/(-a1+delta) for
+    -a1 >= 0 and th = (-a1-delta)/(2 a2) otherwise (neither cancels in its branch);
     inside the knot range the two agree to <=1e-12 in fp64 (pinned by the goldens,
     which only compare there), and the stable form is additionally pinned by the
     forward round trip.
@@ -224,7 +225,9 @@ def rqs_invert(kx, ky, kd, w, axis=1):
     a1 = -a2 - s
     a0 = s * eta
     delta = torch.sqrt(a1 * a1 - 4 * a0 * a2)
-    th = 2 * a0 / (-a1 + delta)
+    bb = -a1
+    safe = lambda t: torch.where(t == 0, torch.ones_like(t), t)
+    th = torch.where(bb >= 0, 2 * a0 / safe(bb + delta), (bb - delta) / safe(2 * a2))
     return x0 + (x1 - x0) * th, 1 / _grad_at(th, s, d0, curv)
 
 
