@@ -181,7 +181,11 @@ def main():
     assert bool(torch.isfinite(logJ).all()) and bool(torch.isfinite(y).all())
 
     if rank == 0:
-        pipeline_pair = False     # the layout the timed pipeline feeds the kernel with
+        # the layout the timed pipeline feeds the coupling kernel with (pair-compact when the
+        # parameter net is this package's ConvAct on a plain even-odd mask)
+        with torch.no_grad():
+            probe = torch.zeros((1,) + lattice, device=dev, dtype=torch.float32)
+            pipeline_pair = cpl._params(cpl.nets[0], probe, parity=0)[1] == 1
         kt = time_rqs_kernel(cpl, lattice, a.knots, dev, a.kernel_reps, pipeline_pair)
         kt_pair = time_rqs_kernel(cpl, lattice, a.knots, dev, a.kernel_reps, True)
         cfgs = a.batch * world * a.steps

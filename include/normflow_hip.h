@@ -164,6 +164,28 @@ int nf_distconv_vjp(const void *v, const void *knots, int K, const void *grad_ou
                     int64_t V, int stages, int inverse, void *workspace,
                     size_t workspace_bytes, int dtype, void *stream);
 
+/* ---- K5: circular 'same' convolution + bias + activation on the f32 matrix cores ----
+ * Replaces one Conv{1,2,3}d(padding='same', padding_mode='circular') / Conv4d layer of
+ * ConvAct together with the activation that follows it (src/nn/scalar/modules.py:120-145,
+ * src/nn/scalar/convNd.py:86-126).  Lattices of dimension d < 4 are passed with leading
+ * axes of extent 1 and kernel extent 1.
+ *
+ *   in      (B, cin, V) f32, channel planes (the layout of a torch (B, C, *L) tensor)
+ *   wfrag   weights in MFMA-fragment order: [tap][ceil(cin/4)][ceil(cout/16)][4][16] with
+ *           wfrag[t][q][n][g][j] = W[16n + j][4q + g][t] (0 where out of range), taps in
+ *           row-major kernel order
+ *   bias    (cout) or NULL
+ *   out     (B, cout, V), or with compact != 0 (B, cout, V/2): only the site of every
+ *           aligned pair (2h, 2h+1) whose coordinate sum has parity `active_parity`
+ *           (NF_LAYOUT_PAIR input of the coupling kernels)
+ *   act     0 none, 1 tanh, 2 relu, 3 leaky_relu(0.01), 4 softplus, 5 abs, 6 sigmoid
+ */
+int nf_conv_cin_pad(int cin);
+int nf_conv_ntiles(int cout);
+int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, void *out, int64_t B,
+                const int32_t *lattice, const int32_t *ksize, int cin, int cout, int act,
+                int compact, int active_parity, int dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

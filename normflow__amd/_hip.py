@@ -50,6 +50,10 @@ PROTOTYPES = {
     "nf_affine_vjp": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _I, _I, _P]),
     "nf_distconv": (_I, [_P, _P, _I, _P, _P, _P, _I64, _I64, _I, _I, _P, _SZ, _I, _P]),
     "nf_distconv_vjp": (_I, [_P, _P, _I, _P, _P, _P, _P, _I64, _I64, _I, _I, _P, _SZ, _I, _P]),
+    "nf_conv_cin_pad": (_I, [_I]),
+    "nf_conv_ntiles": (_I, [_I]),
+    "nf_conv_fwd": (_I, [_P, _P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I, _I, _I,
+                         _I, _P]),
 }
 
 _lib = None
@@ -347,3 +351,99 @@ class DistConvFn(torch.autograd.Function):
             gk += part
         gk = gk.to(knots.dtype) if knots is not None else None
         return gin, gk, (glogj if ctx.has_log0 else None), None, None
+
+
+# ============================================================================== conv
+ACT_CODES = {None: 0, 'none': 0, 'tanh': 1, 'relu': 2, 'leaky_relu': 3, 'softplus': 4, 'abs': 5, 'expit': 6}
+_TORCH_ACT = {0: lambda t: t, 1: torch.tanh, 2: torch.relu,
+              3: lambda t: torch.nn.functional.leaky_relu(t), 4: lambda t: torch.nn.functional.softplus(t),
+              5: torch.abs, 6: torch.sigmoid}
+
+
+def pack_conv_weight(w):
+    """(Cout, Cin, *k) -> MFMA fragment order [tap][cin/4][cout/16][4][16] (zero padded)."""
+    cout, cin = w.shape[:2]
+    ntaps = 1
+    for k in w.shape[2:]:
+        ntaps *= k
+    cin_pad, nt = (cin + 3) // 4 * 4, (cout + 15) // 16
+    wp = w.new_zeros(nt * 16, cin_pad, ntaps)
+    wp[:cout, :cin] = w.reshape(cout, cin, ntaps)
+    return wp.reshape(nt, 16, cin_pad // 4, 4, ntaps).permute(4, 2, 0, 3, 1).contiguous()
+
+
+def conv_supported(x, weight):
+    return x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and 1 <= x.dim() - 2 <= 4
+
+
+def _conv_launch(x, wfrag, bias, ksize, cout, act, compact, parity):
+    lib = load()
+    B, cin = x.shape[:2]
+    lat = list(x.shape[2:])
+    d = len(lat)
+    lat4 = (C.c_int32 * 4)(*([1] * (4 - d) + lat))
+    k4 = (C.c_int32 * 4)(*([1] * (4 - d) + list(ksize)))
+    V = 1
+    for n in lat:
+        V *= n
+    out = torch.empty((B, cout, V // 2) if compact else (B, cout) + tuple(lat), dtype=x.dtype, device=x.device)
+    for b0 in range(0, B, MAX_B):
+        b1 = min(B, b0 + MAX_B)
+        _check(lib.nf_conv_fwd(_ptr(x[b0:b1]), _ptr(wfrag), _ptr(bias), _ptr(out[b0:b1]), b1 - b0, lat4, k4,
+                               cin, cout, act, int(compact), int(parity), NF_F32, _stream()), "nf_conv_fwd")
+    return out
+
+
+def _compact_to_full(t, lattice, parity):
+    """(B, C, V/2) pair-compact -> (B, C, *L) with zeros at the other sites (host-side helper
+    of the conv VJP; the checkerboard is rebuilt from the coordinate sum)."""
+    B, Cc, Vh = t.shape
+    total = torch.zeros(tuple(lattice), dtype=torch.int64, device=t.device)
+    for mu, n in enumerate(lattice):
+        view = [1] * len(lattice)
+        view[mu] = n
+        total = total + torch.arange(n, device=t.device).reshape(view)
+    first = ((total.reshape(-1, 2)[:, 0] % 2) == parity)
+    z = torch.zeros_like(t)
+    full = torch.stack((torch.where(first, t, z), torch.where(first, z, t)), dim=-1)
+    return full.reshape(B, Cc, *lattice)
+
+
+class ConvFn(torch.autograd.Function):
+    """One circular conv layer + activation.  Forward: the MFMA kernel.  Backward: not yet a
+    HIP kernel -- the cotangents are obtained by differentiating this package's torch-op
+    restatement of the same layer (nn/scalar/convNd.circular_conv)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, compact, parity):
+        _require_device(x, weight, bias)
+        x = x.contiguous()
+        out = _conv_launch(x, pack_conv_weight(weight), bias, weight.shape[2:], weight.shape[0], act,
+                           compact, parity)
+        ctx.save_for_backward(x, weight, bias)
+        ctx.act, ctx.compact, ctx.parity = act, compact, parity
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from .nn.scalar.convNd import circular_conv
+        x, weight, bias = ctx.saved_tensors
+        if ctx.compact:
+            gout = _compact_to_full(gout, x.shape[2:], ctx.parity)
+        with torch.enable_grad():
+            xs = x.detach().requires_grad_(True)
+            ws = weight.detach().requires_grad_(True)
+            bs = bias.detach().requires_grad_(True) if bias is not None else None
+            y = _TORCH_ACT[ctx.act](circular_conv(xs, ws, bs, force_torch=True))
+            ins = [xs, ws] + ([bs] if bs is not None else [])
+            grads = torch.autograd.grad(y, ins, gout.reshape(y.shape))
+        return grads[0], grads[1], (grads[2] if bs is not None else None), None, None, None
+
+
+def conv_layer(x, weight, bias, act=0, compact=False, parity=0):
+    """Circular 'same' conv + activation on the HIP kernel; differentiable."""
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+        return ConvFn.apply(x, weight, bias, act, compact, parity)
+    x = x.contiguous()
+    return _conv_launch(x, pack_conv_weight(weight.detach()), None if bias is None else bias.detach(),
+                        weight.shape[2:], weight.shape[0], act, compact, parity)

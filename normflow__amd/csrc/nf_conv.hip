@@ -1,0 +1,305 @@
+// nf_conv.hip -- K5: circular 'same' convolution (lattice dimension 1..4) as an implicit
+// GEMM on the f32 matrix cores (v_mfma_f32_16x16x4_f32: exact f32 products and
+// accumulation, same numerics as an fmaf chain), with bias + activation fused and an
+// optional "active sites only, pair-compact" output for the layer that feeds a coupling
+// kernel (include/normflow_hip.h, NF_LAYOUT_PAIR).
+//
+// Restates what ConvAct computes (reference: src/nn/scalar/modules.py:120-145 -- a chain of
+// torch Conv{1,2,3}d(padding='same', padding_mode='circular') / Conv4d + activation;
+// Conv4d itself is src/nn/scalar/convNd.py:86-126: k0 shifted 3-d convolutions summed):
+//     out[b,o,n] = bias[o] + sum_{i,j} W[o,i,j] * in[b,i,(n + j - k//2) mod L]
+//
+// Mapping (one workgroup = one sample x one box of output sites):
+//   * the input box plus its halo, all input channels, is staged in LDS as channel planes
+//     (plane stride chosen so that the 4 k-groups of an MFMA A-fragment hit disjoint banks);
+//   * GEMM view: rows M = output sites (16 per MFMA tile), columns N = output channels
+//     (16 per tile), reduction K = (tap, input channel), 4 per MFMA;
+//   * A fragments (site, channel) are LDS reads at  lane_base + tap_offset + plane;
+//     B fragments (weights) are pre-packed on the host side in fragment order and read
+//     straight from global memory (a few KB per layer, L1/L2 resident, one coalesced
+//     256-B row per fragment) -- no LDS spent on them;
+//   * every wave owns MT site tiles x NT channel tiles of accumulators (MT*NT independent
+//     chains cover the 40-cycle MFMA latency);
+//   * epilogue: bias, activation, store as channel planes (B, Cout, V) -- the layout torch
+//     uses, so the kernel drops in for the torch convolution -- or, in pair-compact mode,
+//     only the ACTIVE site of every aligned site pair, to (B, Cout, V/2).
+#include "nf_internal.h"
+
+namespace nf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { kActNone = 0, kActTanh = 1, kActRelu = 2, kActLeakyRelu = 3, kActSoftplus = 4, kActAbs = 5,
+       kActSigmoid = 6 };
+
+struct ConvArgs {
+  const float *in;      // (B, Cin, V)
+  const float *wfrag;   // [tap][kq][ntile][64] fragment-ordered, zero padded
+  const float *bias;    // (Cout) or null
+  float *out;           // (B, Cout, V) or (B, Cout, V/2)
+  int64_t V;
+  int L[4], k[4], box[4], lbox[4], nbox[4], hal[4];
+  int S;                // LDS plane stride (dwords)
+  int cin, cin_pad, cout, kq, nt_total, nt0;
+  int act, compact, parity;
+};
+
+__device__ __forceinline__ float activate(float v, int act) {
+  switch (act) {
+    case kActTanh: return tanhf(v);
+    case kActRelu: return v > 0.f ? v : 0.f;
+    case kActLeakyRelu: return v > 0.f ? v : 0.01f * v;
+    case kActSoftplus: return v > 20.f ? v : log1pf(expf(v));
+    case kActAbs: return fabsf(v);
+    case kActSigmoid: return 1.f / (1.f + expf(-v));
+    default: return v;
+  }
+}
+
+__device__ __forceinline__ int wrap(int v, int L) {
+  v %= L;
+  return v < 0 ? v + L : v;
+}
+
+template <int MT, int NT, bool COMPACT>
+__global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
+  extern __shared__ __align__(16) float tile[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = kBlock / kWave;
+  // ---- which box
+  int bid = blockIdx.x;
+  int o[4];
+#pragma unroll
+  for (int mu = 3; mu >= 0; --mu) {
+    o[mu] = (bid % A.nbox[mu]) * A.box[mu];
+    bid /= A.nbox[mu];
+  }
+  const int b = blockIdx.y;
+  const float *__restrict__ in_b = A.in + int64_t(b) * A.cin * A.V;
+  const int r0 = A.k[0] >> 1, r1 = A.k[1] >> 1, r2 = A.k[2] >> 1, r3 = A.k[3] >> 1;
+  const int h0 = A.hal[0], h1 = A.hal[1], h2 = A.hal[2], h3 = A.hal[3];
+
+  // ---- stage the input box + halo: one (channel, z0, z1, z2) row per wave iteration
+  const int rows_per_c = h0 * h1 * h2;
+  const int nrows = rows_per_c * A.cin_pad;
+  for (int row = wave; row < nrows; row += nwaves) {
+    const int c = row / rows_per_c;
+    int rem = row - c * rows_per_c;
+    const int z0 = rem / (h1 * h2);
+    rem -= z0 * h1 * h2;
+    const int z1 = rem / h2, z2 = rem - z1 * h2;
+    const int x0 = wrap(o[0] + z0 - r0, A.L[0]), x1 = wrap(o[1] + z1 - r1, A.L[1]),
+              x2 = wrap(o[2] + z2 - r2, A.L[2]);
+    const int64_t rowbase = ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3];
+    float *dst = tile + c * A.S + ((z0 * h1 + z1) * h2 + z2) * h3;
+    const float *src = in_b + int64_t(c) * A.V + rowbase;
+    for (int z3 = lane; z3 < h3; z3 += kWave) {
+      const int x3 = wrap(o[3] + z3 - r3, A.L[3]);
+      dst[z3] = c < A.cin ? src[x3] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  // ---- per-lane A-fragment bases: unit -> box coordinates (box dims are powers of two)
+  const int g = lane >> 4;                       // k-group of the MFMA fragment
+  const int lb3 = COMPACT ? A.lbox[3] - 1 : A.lbox[3];
+  int abase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int u = ((wave * MT + mt) << 4) + (lane & 15);
+    const int p3 = u & ((1 << lb3) - 1);
+    u >>= lb3;
+    const int z2 = u & (A.box[2] - 1);
+    u >>= A.lbox[2];
+    const int z1 = u & (A.box[1] - 1);
+    u >>= A.lbox[1];
+    const int z0 = u;
+    int z3 = p3;
+    if (COMPACT) z3 = 2 * p3 + ((A.parity + o[0] + z0 + o[1] + z1 + o[2] + z2) & 1);
+    abase[mt] = ((z0 * h1 + z1) * h2 + z2) * h3 + z3 + g * A.S;
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- main loop over taps (uniform) and channel quads
+  const float *__restrict__ wf = A.wfrag + (int64_t(A.nt0) << 6) + lane;
+  const int wstep = A.nt_total << 6;             // floats per (tap, kq)
+  int tap = 0;
+  for (int j0 = 0; j0 < A.k[0]; ++j0)
+    for (int j1 = 0; j1 < A.k[1]; ++j1)
+      for (int j2 = 0; j2 < A.k[2]; ++j2)
+        for (int j3 = 0; j3 < A.k[3]; ++j3, ++tap) {
+          const int toff = ((j0 * h1 + j1) * h2 + j2) * h3 + j3;
+          const float *__restrict__ wt = wf + int64_t(tap) * A.kq * wstep;
+          for (int kq = 0; kq < A.kq; ++kq) {
+            float bf[NT], af[MT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bf[nt] = wt[kq * wstep + (nt << 6)];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = tile[abase[mt] + toff + 4 * kq * A.S];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+          }
+        }
+
+  // ---- epilogue: C/D layout  col = lane&15 (channel), row = 4*(lane>>4) + reg (site)
+  const int64_t Vout = COMPACT ? A.V / 2 : A.V;
+  float *__restrict__ out_b = A.out + int64_t(b) * A.cout * Vout;
+  const int L3u = COMPACT ? A.L[3] / 2 : A.L[3];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    // the 4 units of this lane: consecutive along the fastest box axis (box3 units >= 4 is
+    // guaranteed by the launcher), so they share z0..z2 and form one 16-byte store
+    int u = ((wave * MT + mt) << 4) + (g << 2);
+    const int p3 = u & ((1 << lb3) - 1);
+    u >>= lb3;
+    const int z2 = u & (A.box[2] - 1);
+    u >>= A.lbox[2];
+    const int z1 = u & (A.box[1] - 1);
+    u >>= A.lbox[1];
+    const int z0 = u;
+    const int x0 = o[0] + z0, x1 = o[1] + z1, x2 = o[2] + z2;
+    const int x3u = (COMPACT ? o[3] / 2 : o[3]) + p3;
+    const bool row_ok = x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2];
+    const int64_t base = ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * L3u + x3u;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co = ((A.nt0 + nt) << 4) + (lane & 15);
+      if (!row_ok || co >= A.cout) continue;
+      const float bv = A.bias ? A.bias[co] : 0.f;
+      f32x4 v = acc[mt][nt];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = activate(v[r] + bv, A.act);
+      float *dst = out_b + int64_t(co) * Vout + base;
+      if (x3u + 3 < L3u && ((Vout | base) & 3) == 0) {
+        *reinterpret_cast<f32x4 *>(dst) = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (x3u + r < L3u) dst[r] = v[r];
+      }
+    }
+  }
+}
+
+static int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+template <int MT, int NT>
+static void launch(const ConvArgs &A, dim3 grid, size_t lds, hipStream_t stream) {
+  if (A.compact) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<MT, NT, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    hipLaunchKernelGGL((conv_kernel<MT, NT, true>), grid, dim3(kBlock), lds, stream, A);
+  } else {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<MT, NT, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    hipLaunchKernelGGL((conv_kernel<MT, NT, false>), grid, dim3(kBlock), lds, stream, A);
+  }
+}
+
+}  // namespace nf
+
+using namespace nf;
+
+extern "C" int nf_conv_cin_pad(int cin) { return (cin + 3) & ~3; }
+extern "C" int nf_conv_ntiles(int cout) { return (cout + 15) >> 4; }
+
+extern "C" int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, void *out, int64_t B,
+                           const int32_t *lattice, const int32_t *ksize, int cin, int cout, int act,
+                           int compact, int active_parity, int dtype, void *stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  NF_REQUIRE(dtype == NF_F32, "nf_conv_fwd: only NF_F32 is implemented (got dtype %d)", dtype);
+  NF_REQUIRE(in && wfrag && out && lattice && ksize, "nf_conv_fwd: NULL pointer");
+  NF_REQUIRE(B >= 0 && B <= 65535, "nf_conv_fwd: batch %lld outside [0, 65535]", (long long)B);
+  NF_REQUIRE(cin >= 1 && cout >= 1, "nf_conv_fwd: bad channel counts");
+  NF_REQUIRE(act >= kActNone && act <= kActSigmoid, "nf_conv_fwd: unknown activation code %d", act);
+  ConvArgs A{};
+  int64_t V = 1;
+  for (int mu = 0; mu < 4; ++mu) {
+    NF_REQUIRE(lattice[mu] >= 1 && ksize[mu] >= 1 && (ksize[mu] & 1), "nf_conv_fwd: lattice dims >= 1 and odd kernel sizes needed");
+    A.L[mu] = lattice[mu];
+    A.k[mu] = ksize[mu];
+    V *= lattice[mu];
+  }
+  if (compact) NF_REQUIRE(A.L[3] % 2 == 0, "nf_conv_fwd: pair-compact output needs an even fastest axis");
+  if (B == 0 || V == 0) return NF_OK;
+  A.in = static_cast<const float *>(in);
+  A.wfrag = static_cast<const float *>(wfrag);
+  A.bias = static_cast<const float *>(bias);
+  A.out = static_cast<float *>(out);
+  A.V = V;
+  A.cin = cin; A.cin_pad = (cin + 3) & ~3; A.cout = cout; A.kq = A.cin_pad / 4;
+  A.nt_total = (cout + 15) >> 4;
+  A.act = act; A.compact = compact ? 1 : 0; A.parity = active_parity & 1;
+
+  // ---- box: 256 output units per workgroup (4 waves x MT=4 tiles x 16), powers of two,
+  // long along the fastest axis (coalescing), then as cubic as the lattice allows (halo).
+  const int MT = 4;
+  const int units = (kBlock / kWave) * MT * 16;
+  const int target = compact ? 2 * units : units;        // sites in the box
+  int box[4] = {1, 1, 1, 1};
+  int cap[4];
+  for (int mu = 0; mu < 4; ++mu) cap[mu] = 1 << ilog2(A.L[mu]);
+  box[3] = cap[3] < 32 ? cap[3] : 32;
+  const int min3 = compact ? 8 : 4;                       // >= 4 units along the fastest axis
+  if (box[3] < min3) box[3] = min3;
+  int vol = box[3];
+  while (vol < target) {
+    int best = -1;
+    for (int mu = 2; mu >= 0; --mu)
+      if (box[mu] < cap[mu] && (best < 0 || box[mu] < box[best])) best = mu;
+    if (best < 0) {
+      if (box[3] < cap[3]) best = 3; else break;
+    }
+    box[best] *= 2;
+    vol *= 2;
+  }
+  while (vol < target) {   // tiny lattice: pad the fastest axis (extra units are masked out)
+    box[3] *= 2;
+    vol *= 2;
+  }
+  int64_t nblocks = 1;
+  int64_t halvol = 1;
+  for (int mu = 0; mu < 4; ++mu) {
+    A.box[mu] = box[mu];
+    A.lbox[mu] = ilog2(box[mu]);
+    A.nbox[mu] = (A.L[mu] + box[mu] - 1) / box[mu];
+    A.hal[mu] = box[mu] + A.k[mu] - 1;
+    nblocks *= A.nbox[mu];
+    halvol *= A.hal[mu];
+  }
+  // plane stride: odd for the stride-2 reads of compact mode, = 16 mod 32 otherwise, so the
+  // four k-groups of an A fragment fall on disjoint LDS banks
+  int S = int(halvol);
+  if (compact) S |= 1; else S = ((S + 15) & ~31) + 16;
+  A.S = S;
+  const size_t lds = size_t(A.cin_pad) * S * sizeof(float);
+  NF_REQUIRE(lds <= 160 * 1024, "nf_conv_fwd: input box needs %zu B of LDS (> 160 KiB): cin=%d, kernel %dx%dx%dx%d",
+             lds, cin, A.k[0], A.k[1], A.k[2], A.k[3]);
+  NF_REQUIRE(nblocks <= 0x7fffffff, "nf_conv_fwd: lattice too large");
+  const dim3 grid = dim3(static_cast<unsigned>(nblocks), static_cast<unsigned>(B), 1u);
+  for (int nt0 = 0; nt0 < A.nt_total; nt0 += 3) {
+    A.nt0 = nt0;
+    const int n = A.nt_total - nt0 >= 3 ? 3 : A.nt_total - nt0;
+    if (n == 3) launch<4, 3>(A, grid, lds, stream);
+    else if (n == 2) launch<4, 2>(A, grid, lds, stream);
+    else launch<4, 1>(A, grid, lds, stream);
+    const int rc = check_launch("conv kernel");
+    if (rc) return rc;
+  }
+  return NF_OK;
+}

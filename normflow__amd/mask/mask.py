@@ -63,6 +63,18 @@ class Mask(torch.nn.Module):
             self._pairable = ok
         return self._pairable
 
+    def checkerboard_parity(self, channel):
+        """a in {0, 1} if `channel` is exactly the set of sites with coordinate sum = a (mod 2)
+        (a plain even-odd mask), else None.  Lets the parameter net emit its output at the
+        active sites only."""
+        if not hasattr(self, '_cb'):
+            m = self._mask.cpu()
+            par = (_index_sum(m.shape) % 2).to(torch.uint8)
+            self._cb = 0 if torch.equal(m, 1 - par) else (1 if torch.equal(m, par) else None)
+        if self._cb is None:
+            return None
+        return self._cb if channel == 0 else 1 - self._cb
+
     @staticmethod
     def make_mask(**kwargs):
         raise NotImplementedError

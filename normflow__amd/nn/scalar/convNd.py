@@ -25,9 +25,15 @@ def wrap_pad(x, pads):
     return x
 
 
-def circular_conv(x, weight, bias=None):
+def circular_conv(x, weight, bias=None, force_torch=False):
     """Circular 'same' cross-correlation for 1..4 lattice dimensions.
-    x: (B, Cin, *L); weight: (Cout, Cin, *k), k odd; bias: (Cout,) | None."""
+    x: (B, Cin, *L); weight: (Cout, Cin, *k), k odd; bias: (Cout,) | None.
+
+    fp32 tensors on the GPU go to the MFMA kernel (nf_conv_fwd); other dtypes / devices,
+    and the kernel's own VJP, use the torch-op decomposition below."""
+    from ... import _hip
+    if not force_torch and _hip.conv_supported(x, weight):
+        return _hip.conv_layer(x, weight, bias)
     d = x.dim() - 2
     ks = tuple(weight.shape[2:])
     if d <= 3:

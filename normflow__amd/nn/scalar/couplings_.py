@@ -100,8 +100,16 @@ class Coupling_(Module_, ABC):
             raise NotImplementedError("propagate_density=True (per-site densities) is not provided by "
                                       "the fused kernels, which reduce log|J| per sample")
 
-    def _params(self, net, x_frozen):
-        """Run the parameter net; return raw logits as (B, C, V) and the layout code."""
+    def _params(self, net, x_frozen, parity=None):
+        """Run the parameter net; return raw logits as (B, C, V) [or (B, C, V/2)] and the
+        layout code.  A ConvAct on a plain even-odd mask emits only the active sites."""
+        if (parity is not None and self.channels_axis == 1 and hasattr(net, 'forward_active')
+                and getattr(self.mask, 'pairable', False) and hasattr(self.mask, 'checkerboard_parity')):
+            a = self.mask.checkerboard_parity(parity)
+            if a is not None:
+                out = net.forward_active(self.preprocess_fz(x_frozen), a)
+                if out is not None:
+                    return out, _hip.LAYOUT_PAIR
         out = net(self.preprocess_fz(x_frozen))
         if self.channels_axis not in (1, 1 - out.dim()):
             out = out.movedim(self.channels_axis, 1)
@@ -122,7 +130,7 @@ class Coupling_(Module_, ABC):
         per_sample = n_out_hint * v.shape[1] * v.element_size()
         vals, logs = [], []
         for b0, b1 in self._slabs(B, per_sample):
-            params, layout = self._params(net, x_frozen[b0:b1])
+            params, layout = self._params(net, x_frozen[b0:b1], parity)
             val, lj = kernel(v[b0:b1], params, None if l0 is None else l0[b0:b1], act, layout)
             vals.append(val)
             logs.append(lj)

@@ -31,6 +31,10 @@ ACTIVATIONS = torch.nn.ModuleDict({
 })
 
 
+_ACT_OF_MODULE = {torch.nn.Tanh: 1, torch.nn.ReLU: 2, torch.nn.LeakyReLU: 3, torch.nn.Softplus: 4, Abs: 5,
+                  torch.nn.Sigmoid: 6, torch.nn.Identity: 0}
+
+
 class PlusBias(torch.nn.Module):
     def __init__(self, out_features):
         super().__init__()
@@ -72,6 +76,54 @@ class ConvAct(torch.nn.Sequential):
         if scale_factor != 1:
             raise NotImplementedError("kernel rescaling on transfer is not supported")
         return copy.deepcopy(self)
+
+    # ---- fused execution: every (conv, activation) pair is ONE launch of the MFMA kernel
+    def _plan(self):
+        """[(conv module, act code)] if the whole stack maps onto nf_conv_fwd, else None."""
+        mods, plan, i = list(self), [], 0
+        while i < len(mods):
+            conv = mods[i]
+            if not isinstance(conv, (torch.nn.Conv1d, torch.nn.Conv2d, torch.nn.Conv3d, Conv4d)):
+                return None
+            if not isinstance(conv, Conv4d):
+                same = conv.padding == 'same' or all(p == k // 2 for p, k in zip(conv.padding, conv.kernel_size))
+                ok = (conv.padding_mode == 'circular' and same and all(k % 2 for k in conv.kernel_size)
+                      and all(s == 1 for s in conv.stride) and all(dl == 1 for dl in conv.dilation)
+                      and conv.groups == 1)
+                if not ok:
+                    return None
+            act = 0
+            if i + 1 < len(mods) and not any(True for _ in mods[i + 1].parameters()):
+                code = _ACT_OF_MODULE.get(type(mods[i + 1]))
+                if code is None:
+                    return None
+                act = code
+                i += 1
+            plan.append((conv, act))
+            i += 1
+        return plan
+
+    def _run_fused(self, x, compact_parity=None):
+        plan = self._plan()
+        if plan is None or not _hip.conv_supported(x, plan[0][0].weight) or x.dim() - 2 != self.conv_kwargs['conv_dim']:
+            return None
+        for n, (conv, act) in enumerate(plan):
+            last = n == len(plan) - 1
+            x = _hip.conv_layer(x, conv.weight, conv.bias, act,
+                                compact=last and compact_parity is not None,
+                                parity=compact_parity or 0)
+        return x
+
+    def forward(self, x):
+        out = self._run_fused(x) if self.conv_kwargs.get('pre_act') is None else None
+        return out if out is not None else super().forward(x)
+
+    def forward_active(self, x, active_parity):
+        """Raw output at the ACTIVE sites only, pair-compact (B, C, V/2): the sites whose
+        coordinate sum has parity `active_parity`.  None if the fused path does not apply."""
+        if self.conv_kwargs.get('pre_act') is not None or x.shape[-1] % 2:
+            return None
+        return self._run_fused(x, compact_parity=active_parity)
 
 
 class LinearAct(torch.nn.Sequential):
