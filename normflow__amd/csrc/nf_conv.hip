@@ -23,6 +23,7 @@
 //   * epilogue: bias, activation, store as channel planes (B, Cout, V) -- the layout torch
 //     uses, so the kernel drops in for the torch convolution -- or, in pair-compact mode,
 //     only the ACTIVE site of every aligned site pair, to (B, Cout, V/2).
+#include <cstdlib>
 #include "nf_internal.h"
 
 namespace nf {
@@ -42,6 +43,7 @@ struct ConvArgs {
   int S;                // LDS plane stride (dwords)
   int cin, cin_pad, cout, kq, nt_total, nt0;
   int act, compact, parity;
+  int dbg;              // profiling ablation (NF_CONV_DBG): bit0 skip staging, bit1 skip the MFMA loop
 };
 
 __device__ __forceinline__ float activate(float v, int act) {
@@ -61,12 +63,100 @@ __device__ __forceinline__ int wrap(int v, int L) {
   return v < 0 ? v + L : v;
 }
 
+// Tap counters (uniform): row-major walk over the kernel window; `off` is the LDS offset of
+// the tap relative to a unit's own position in the staged tile.
+struct TapWalk {
+  int j1, j2, j3, off, tap;
+  __device__ __forceinline__ void next(const ConvArgs &A, int ntaps) {
+    if (tap + 1 >= ntaps) return;               // clamp at the last tap (harmless re-read)
+    ++tap;
+    const int h3 = A.hal[3], h2 = A.hal[2], h1 = A.hal[1];
+    ++off;
+    if (++j3 == A.k[3]) {
+      j3 = 0;
+      off += h3 - A.k[3];
+      if (++j2 == A.k[2]) {
+        j2 = 0;
+        off += (h2 - A.k[2]) * h3;
+        if (++j1 == A.k[1]) {
+          j1 = 0;
+          off += (h1 - A.k[1]) * h2 * h3;
+        }
+      }
+    }
+  }
+};
+
+template <int MT, int NT, int KQ>
+__device__ __forceinline__ void mma_taps(const ConvArgs &A, const float *tile, const int (&abase)[MT],
+                                         const float *__restrict__ wf, f32x4 (&acc)[MT][NT]) {
+  const int ntaps = A.k[0] * A.k[1] * A.k[2] * A.k[3];
+  const int wstep = A.nt_total << 6;             // floats per (tap, kq)
+  const int S4 = 4 * A.S;
+  if constexpr (KQ == 0) {                       // any channel count: plain loop
+    TapWalk w{0, 0, 0, 0, 0};
+    for (int t = 0; t < ntaps; ++t) {
+      for (int q = 0; q < A.kq; ++q) {
+        float a[MT], b[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = wf[(int64_t(t) * A.kq + q) * wstep + (nt << 6)];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = tile[abase[mt] + w.off + q * S4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+      }
+      w.next(A, ntaps);
+    }
+  } else {
+    float a0[KQ][MT], b0[KQ][NT], a1[KQ][MT], b1[KQ][NT];
+    auto request = [&](float (&a)[KQ][MT], float (&b)[KQ][NT], const TapWalk &w) {
+      const float *__restrict__ wt = wf + int64_t(w.tap) * (KQ * wstep);
+#pragma unroll
+      for (int q = 0; q < KQ; ++q)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[q][nt] = wt[q * wstep + (nt << 6)];
+#pragma unroll
+      for (int q = 0; q < KQ; ++q)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[q][mt] = tile[abase[mt] + w.off + q * S4];
+    };
+    auto multiply = [&](const float (&a)[KQ][MT], const float (&b)[KQ][NT]) {
+#pragma unroll
+      for (int q = 0; q < KQ; ++q)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][mt], b[q][nt], acc[mt][nt], 0, 0, 0);
+    };
+    TapWalk w{0, 0, 0, 0, 0};
+    request(a0, b0, w);
+    for (int t = 0; t < ntaps; t += 2) {
+      w.next(A, ntaps);
+      request(a1, b1, w);
+      __builtin_amdgcn_sched_barrier(0);     // keep the requests AHEAD of this tap's MFMAs
+      multiply(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < ntaps) {
+        w.next(A, ntaps);
+        request(a0, b0, w);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+}
+
 template <int MT, int NT, bool COMPACT>
 __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
   extern __shared__ __align__(16) float tile[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nwaves = kBlock / kWave;
+  constexpr int nwaves = kBlock / kWave;
   // ---- which box
   int bid = blockIdx.x;
   int o[4];
@@ -80,23 +170,44 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
   const int r0 = A.k[0] >> 1, r1 = A.k[1] >> 1, r2 = A.k[2] >> 1, r3 = A.k[3] >> 1;
   const int h0 = A.hal[0], h1 = A.hal[1], h2 = A.hal[2], h3 = A.hal[3];
 
-  // ---- stage the input box + halo: one (channel, z0, z1, z2) row per wave iteration
-  const int rows_per_c = h0 * h1 * h2;
-  const int nrows = rows_per_c * A.cin_pad;
-  for (int row = wave; row < nrows; row += nwaves) {
-    const int c = row / rows_per_c;
-    int rem = row - c * rows_per_c;
-    const int z0 = rem / (h1 * h2);
-    rem -= z0 * h1 * h2;
-    const int z1 = rem / h2, z2 = rem - z1 * h2;
-    const int x0 = wrap(o[0] + z0 - r0, A.L[0]), x1 = wrap(o[1] + z1 - r1, A.L[1]),
-              x2 = wrap(o[2] + z2 - r2, A.L[2]);
-    const int64_t rowbase = ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3];
-    float *dst = tile + c * A.S + ((z0 * h1 + z1) * h2 + z2) * h3;
-    const float *src = in_b + int64_t(c) * A.V + rowbase;
-    for (int z3 = lane; z3 < h3; z3 += kWave) {
+  // ---- stage the input box + halo.
+  // (1) every thread of the workgroup resolves ONE halo row (z0, z1, z2) -> (offset of that
+  //     row in a channel plane of the input, offset in a channel plane of the LDS tile); the
+  //     divisions / wrap-arounds happen once per row here, in parallel, not in the copy loop;
+  // (2) each wave then copies rows w, w+4, ...: two broadcast LDS reads per row, then per
+  //     channel one coalesced global load and one LDS store, four channels in flight.
+  const int R = h0 * h1 * h2;
+  int *rowsrc = reinterpret_cast<int *>(tile + A.cin_pad * A.S);
+  int *rowdst = rowsrc + R;
+  if (!(A.dbg & 1)) {
+    for (int t = threadIdx.x; t < R; t += kBlock) {
+      const int z0 = t / (h1 * h2), rem = t - z0 * (h1 * h2);
+      const int z1 = rem / h2, z2 = rem - z1 * h2;
+      const int x0 = wrap(o[0] + z0 - r0, A.L[0]), x1 = wrap(o[1] + z1 - r1, A.L[1]),
+                x2 = wrap(o[2] + z2 - r2, A.L[2]);
+      rowsrc[t] = ((x0 * A.L[1] + x1) * A.L[2] + x2) * A.L[3];     // < V <= 2^31 (checked by the launcher)
+      rowdst[t] = t * h3;
+    }
+    for (int i = threadIdx.x; i < (A.cin_pad - A.cin) * A.S; i += kBlock) tile[A.cin * A.S + i] = 0.f;
+    __syncthreads();
+    for (int z3b = 0; z3b < h3; z3b += kWave) {         // 64-wide chunks of the fastest axis
+      const int z3 = z3b + lane;
+      const bool in_row = z3 < h3;
       const int x3 = wrap(o[3] + z3 - r3, A.L[3]);
-      dst[z3] = c < A.cin ? src[x3] : 0.f;
+      for (int r = wave; r < R; r += nwaves) {
+        const int src = rowsrc[r] + x3, dst = rowdst[r] + z3;
+        int c = 0;
+        for (; c + 4 <= A.cin; c += 4) {
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = in_row ? in_b[int64_t(c + i) * A.V + src] : 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (in_row) tile[(c + i) * A.S + dst] = v[i];
+        }
+        for (; c < A.cin; ++c)
+          if (in_row) tile[c * A.S + dst] = in_b[int64_t(c) * A.V + src];
+      }
     }
   }
   __syncthreads();
@@ -126,29 +237,19 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- main loop over taps (uniform) and channel quads
+  // ---- main loop over taps, software pipelined by hand: the A (LDS) and B (global, L1/L2)
+  // fragments of tap t+1 are requested before the KQ*MT*NT MFMAs of tap t issue; the loop is
+  // unrolled twice over two named fragment buffers so that no register rotation (and hence no
+  // early s_waitcnt) sits between a request and its use one tap later.
   const float *__restrict__ wf = A.wfrag + (int64_t(A.nt0) << 6) + lane;
-  const int wstep = A.nt_total << 6;             // floats per (tap, kq)
-  int tap = 0;
-  for (int j0 = 0; j0 < A.k[0]; ++j0)
-    for (int j1 = 0; j1 < A.k[1]; ++j1)
-      for (int j2 = 0; j2 < A.k[2]; ++j2)
-        for (int j3 = 0; j3 < A.k[3]; ++j3, ++tap) {
-          const int toff = ((j0 * h1 + j1) * h2 + j2) * h3 + j3;
-          const float *__restrict__ wt = wf + int64_t(tap) * A.kq * wstep;
-          for (int kq = 0; kq < A.kq; ++kq) {
-            float bf[NT], af[MT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bf[nt] = wt[kq * wstep + (nt << 6)];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) af[mt] = tile[abase[mt] + toff + 4 * kq * A.S];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
-          }
-        }
+  if (!(A.dbg & 2)) {
+    switch (A.kq) {
+      case 1: mma_taps<MT, NT, 1>(A, tile, abase, wf, acc); break;
+      case 2: mma_taps<MT, NT, 2>(A, tile, abase, wf, acc); break;
+      case 4: mma_taps<MT, NT, 4>(A, tile, abase, wf, acc); break;
+      default: mma_taps<MT, NT, 0>(A, tile, abase, wf, acc); break;
+    }
+  }
 
   // ---- epilogue: C/D layout  col = lane&15 (channel), row = 4*(lane>>4) + reg (site)
   const int64_t Vout = COMPACT ? A.V / 2 : A.V;
@@ -245,32 +346,48 @@ extern "C" int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, 
   A.cin = cin; A.cin_pad = (cin + 3) & ~3; A.cout = cout; A.kq = A.cin_pad / 4;
   A.nt_total = (cout + 15) >> 4;
   A.act = act; A.compact = compact ? 1 : 0; A.parity = active_parity & 1;
-
-  // ---- box: 256 output units per workgroup (4 waves x MT=4 tiles x 16), powers of two,
-  // long along the fastest axis (coalescing), then as cubic as the lattice allows (halo).
-  const int MT = 4;
-  const int units = (kBlock / kWave) * MT * 16;
-  const int target = compact ? 2 * units : units;        // sites in the box
-  int box[4] = {1, 1, 1, 1};
-  int cap[4];
-  for (int mu = 0; mu < 4; ++mu) cap[mu] = 1 << ilog2(A.L[mu]);
-  box[3] = cap[3] < 32 ? cap[3] : 32;
-  const int min3 = compact ? 8 : 4;                       // >= 4 units along the fastest axis
-  if (box[3] < min3) box[3] = min3;
-  int vol = box[3];
-  while (vol < target) {
-    int best = -1;
-    for (int mu = 2; mu >= 0; --mu)
-      if (box[mu] < cap[mu] && (best < 0 || box[mu] < box[best])) best = mu;
-    if (best < 0) {
-      if (box[3] < cap[3]) best = 3; else break;
-    }
-    box[best] *= 2;
-    vol *= 2;
+  {
+    static const int dbg = getenv("NF_CONV_DBG") ? atoi(getenv("NF_CONV_DBG")) : 0;
+    A.dbg = dbg;
   }
-  while (vol < target) {   // tiny lattice: pad the fastest axis (extra units are masked out)
-    box[3] *= 2;
-    vol *= 2;
+
+  // ---- box: (4 waves x MT tiles x 16) output units per workgroup, powers of two, long along
+  // the fastest axis (coalescing), then as cubic as the lattice allows (least halo).  MT = 4
+  // unless the staged box would then exceed ~80 KiB of LDS (two workgroups per CU keep one
+  // staging while the other multiplies); then MT = 2.
+  int MT = 4;
+  int box[4];
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const int units = (kBlock / kWave) * MT * 16;
+    const int target = compact ? 2 * units : units;        // sites in the box
+    int cap[4];
+    for (int mu = 0; mu < 4; ++mu) { cap[mu] = 1 << ilog2(A.L[mu]); box[mu] = 1; }
+    box[3] = cap[3] < 32 ? cap[3] : 32;
+    const int min3 = compact ? 8 : 4;                       // >= 4 units along the fastest axis
+    if (box[3] < min3) box[3] = min3;
+    int vol = box[3];
+    while (vol < target) {
+      int best = -1;
+      for (int mu = 2; mu >= 0; --mu)
+        if (box[mu] < cap[mu] && (best < 0 || box[mu] < box[best])) best = mu;
+      if (best < 0) {
+        if (box[3] < cap[3]) best = 3; else break;
+      }
+      box[best] *= 2;
+      vol *= 2;
+    }
+    while (vol < target) {   // tiny lattice: pad the fastest axis (extra units are masked out)
+      box[3] *= 2;
+      vol *= 2;
+    }
+    while (vol > target && box[3] > min3) {   // min3 may have overshot a tiny target
+      box[3] /= 2;
+      vol /= 2;
+    }
+    int64_t hv = 1;
+    for (int mu = 0; mu < 4; ++mu) hv *= box[mu] + A.k[mu] - 1;
+    if (MT == 2 || hv * ((cin + 3) & ~3) * 4 <= 78 * 1024) break;
+    MT = 2;
   }
   int64_t nblocks = 1;
   int64_t halvol = 1;
@@ -287,7 +404,10 @@ extern "C" int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, 
   int S = int(halvol);
   if (compact) S |= 1; else S = ((S + 15) & ~31) + 16;
   A.S = S;
-  const size_t lds = size_t(A.cin_pad) * S * sizeof(float);
+  int64_t rows = 1;
+  for (int mu = 0; mu < 3; ++mu) rows *= A.hal[mu];
+  NF_REQUIRE(V < (int64_t(1) << 31), "nf_conv_fwd: lattice volume must be < 2^31");
+  const size_t lds = size_t(A.cin_pad) * S * sizeof(float) + size_t(rows) * 2 * sizeof(int);
   NF_REQUIRE(lds <= 160 * 1024, "nf_conv_fwd: input box needs %zu B of LDS (> 160 KiB): cin=%d, kernel %dx%dx%dx%d",
              lds, cin, A.k[0], A.k[1], A.k[2], A.k[3]);
   NF_REQUIRE(nblocks <= 0x7fffffff, "nf_conv_fwd: lattice too large");
@@ -295,9 +415,15 @@ extern "C" int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, 
   for (int nt0 = 0; nt0 < A.nt_total; nt0 += 3) {
     A.nt0 = nt0;
     const int n = A.nt_total - nt0 >= 3 ? 3 : A.nt_total - nt0;
-    if (n == 3) launch<4, 3>(A, grid, lds, stream);
-    else if (n == 2) launch<4, 2>(A, grid, lds, stream);
-    else launch<4, 1>(A, grid, lds, stream);
+    if (MT == 4) {
+      if (n == 3) launch<4, 3>(A, grid, lds, stream);
+      else if (n == 2) launch<4, 2>(A, grid, lds, stream);
+      else launch<4, 1>(A, grid, lds, stream);
+    } else {
+      if (n == 3) launch<2, 3>(A, grid, lds, stream);
+      else if (n == 2) launch<2, 2>(A, grid, lds, stream);
+      else launch<2, 1>(A, grid, lds, stream);
+    }
     const int rc = check_launch("conv kernel");
     if (rc) return rc;
   }

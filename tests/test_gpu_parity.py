@@ -457,15 +457,16 @@ def test_conv_kernel_vs_oracle(lattice, cin, cout, k, act):
     xd, wd, bd = (t.to(DEV, torch.float32) for t in (x, w, b))
     out = _hip.conv_layer(xd, wd, bd, _hip.ACT_CODES[act])
     assert out.shape == ref.shape
-    assert rel(out, ref) <= 3e-6
+    tol = 1e-6 + 2e-7 * 0.3 * cin * k ** d        # ~ eps_f32 * sum|a b| over K = cin * k^d terms
+    assert rel(out, ref) <= tol
     out_nb = _hip.conv_layer(xd, wd, None, 0)
-    assert rel(out_nb, O.circular_conv_direct(x, w, None)) <= 3e-6
+    assert rel(out_nb, O.circular_conv_direct(x, w, None)) <= tol
     if lattice[-1] % 2 == 0:
         for parity in (0, 1):
             act_mask = (O.even_odd_mask(lattice, parity=0) == (1 - parity)).reshape(-1).to(DEV)   # coord sum % 2 == parity
             comp = _hip.conv_layer(xd, wd, bd, _hip.ACT_CODES[act], compact=True, parity=parity)
             want = compact(T(ref.reshape(B, cout, -1).numpy(), torch.float64), act_mask.to(torch.uint8))
-            assert comp.shape == want.shape and rel(comp, want) <= 3e-6
+            assert comp.shape == want.shape and rel(comp, want) <= tol
 
 
 def test_convact_fused_matches_torch_path_and_grads():
