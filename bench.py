@@ -188,6 +188,15 @@ def main():
             pipeline_pair = cpl._params(cpl.nets[0], probe, parity=0)[1] == 1
         kt = time_rqs_kernel(cpl, lattice, a.knots, dev, a.kernel_reps, pipeline_pair)
         kt_pair = time_rqs_kernel(cpl, lattice, a.knots, dev, a.kernel_reps, True)
+        # HBM traffic of one launch of this kernel from the committed PMC profile (rocprofv3 cannot
+        # collect counters from inside the bench); only quoted when the launch shape is the profiled one
+        traffic, traffic_src = None, None
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_rqs.json")))
+            if pipeline_pair and prof["slab_batch"] == kt["slab"] and prof["algorithmic_bytes_per_launch"] == kt["algo_bytes"]:
+                traffic, traffic_src = prof["hbm_bytes_per_launch"], "profiles/r01_pmc_rqs.json"
+        except (OSError, KeyError, ValueError):
+            pass
         cfgs = a.batch * world * a.steps
         line = {
             "metric": "lattice configs/sec (forward+logdet)", "value": cfgs / elapsed, "unit": "configs/s",
@@ -200,7 +209,7 @@ def main():
                        "global_batch": a.batch * world, "parallelism": f"dp{world}"},
             "roofline": {"kernel": "nf::rqs_kernel<float,16,fwd>" + ("<pair>" if pipeline_pair else "<full>"),
                          "bound": "hbm", "achieved": kt["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": kt["gbs"] / HBM_PEAK_GBS, "traffic": None,
+                         "frac": kt["gbs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": 1e3 * kt["seconds"], "slab_batch": kt["slab"],
                          "algorithmic_bytes_per_launch": kt["algo_bytes"],
                          "pair_layout_variant": {"achieved": kt_pair["gbs"], "frac": kt_pair["gbs"] / HBM_PEAK_GBS,

@@ -139,14 +139,24 @@ MAX_B = 32768  # the batch is the grid's y extent; larger batches are cut into s
 
 
 # =============================================================================== RQS
-def make_rqs_opts(m, xlim, ylim, extrap, layout):
+def make_rqs_opts(m, xlim, ylim, extrap, layout, knots_x=None, knots_y=None):
+    """knots_x / knots_y: optional contiguous 1-D device tensors of m fixed knot coordinates (of
+    the call's dtype); the limits are then the end knots."""
     extrap = extrap or {}
     for side in ('left', 'right'):
         if extrap.get(side) not in EXTRAP:
             raise NotImplementedError(f"extrapolation {extrap.get(side)!r} is not supported "
                                       "(supported: None, 'linear', 'anti')")
-    return RqsOpts(int(m), EXTRAP[extrap.get('left')], EXTRAP[extrap.get('right')], int(layout),
-                   float(xlim[0]), float(xlim[1]), float(ylim[0]), float(ylim[1]), None, None)
+    if knots_x is not None:
+        xlim = (float(knots_x[0]), float(knots_x[-1]))
+    if knots_y is not None:
+        ylim = (float(knots_y[0]), float(knots_y[-1]))
+    opts = RqsOpts(int(m), EXTRAP[extrap.get('left')], EXTRAP[extrap.get('right')], int(layout),
+                   float(xlim[0]), float(xlim[1]), float(ylim[0]), float(ylim[1]),
+                   knots_x.data_ptr() if knots_x is not None else None,
+                   knots_y.data_ptr() if knots_y is not None else None)
+    opts._keepalive = (knots_x, knots_y)
+    return opts
 
 
 def _rqs_call(fn_name, v, params, mask, log0, opts, strides, B, V):

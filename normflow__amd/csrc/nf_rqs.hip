@@ -38,7 +38,8 @@ struct RqsArgs {
   int64_t units;            // work units per sample: V (full) or V/2 (pair)
   int64_t x_bs, y_bs, p_bs; // batch strides (elements)
   double xlo, xhi, ylo, yhi;
-  int m, el, er, layout, iters;
+  const void *fx, *fy;       // optional fixed knot coordinates (m values of T), LDS-column kernels only
+  int m, el, er, layout, iters, C;
 };
 
 // ------------------------------------------------------------ parameter columns
@@ -61,48 +62,78 @@ template <typename T> struct Site {   // what the scan selects for one site
   int j;
 };
 
-// Softmax numerators in place, then the predicated bin scan.  On return a[0..nb)
-// and a[nb..2nb) hold exp(logit - max); sa/sb their sums.
-template <typename T, int MT, bool ON_Y, typename Col>
-__device__ __forceinline__ Site<T> scan_bins(Col &a, int m_rt, T v, T xlo, T W, T ylo, T H, T &sa,
-                                             T &sb) {
-  const int m = MT > 0 ? MT : m_rt;
+// Channel layout of the logits: [x widths (m-1) | y heights (m-1) | derivatives (m)], where
+// the x (y) block is absent when knots_x (knots_y) is fixed (couplings_.py:236-262).
+struct ChanMap { int ox, oy, od; };
+__device__ __forceinline__ ChanMap chan_map(int m, bool fixx, bool fixy) {
   const int nb = m - 1;
-  T amax = a[0], bmax = a[nb];
+  ChanMap c;
+  c.ox = 0;
+  c.oy = fixx ? 0 : nb;
+  c.od = (fixx ? 0 : nb) + (fixy ? 0 : nb);
+  return c;
+}
+
+// Softmax numerators in place, then the predicated bin scan.  On return the x and y logit
+// blocks of `a` hold exp(logit - max); sa/sb their sums.  With fixed knot coordinates (only
+// reachable in the LDS-column kernel, MT == 0) bin widths come from the fixed array.
+template <typename T, int MT, bool ON_Y, typename Col>
+__device__ __forceinline__ Site<T> scan_bins(Col &a, const RqsArgs &A, T v, T xlo, T W, T ylo, T H, T &sa,
+                                             T &sb) {
+  const int m = MT > 0 ? MT : A.m;
+  const int nb = m - 1;
+  const T *fx = MT > 0 ? nullptr : static_cast<const T *>(A.fx);
+  const T *fy = MT > 0 ? nullptr : static_cast<const T *>(A.fy);
+  const ChanMap cm = chan_map(m, fx != nullptr, fy != nullptr);
+  sa = T(1);
+  sb = T(1);
+  if (!fx) {
+    T amax = a[cm.ox];
 #pragma unroll
-  for (int k = 1; k < nb; ++k) {
-    amax = Num<T>::max(amax, a[k]);
-    bmax = Num<T>::max(bmax, a[nb + k]);
+    for (int k = 1; k < nb; ++k) amax = Num<T>::max(amax, a[cm.ox + k]);
+    sa = T(0);
+#pragma unroll
+    for (int k = 0; k < nb; ++k) {
+      const T e = Num<T>::exp2((a[cm.ox + k] - amax) * Num<T>::kLog2e);
+      a[cm.ox + k] = e;
+      sa += e;
+    }
   }
-  sa = T(0);
-  sb = T(0);
+  if (!fy) {
+    T bmax = a[cm.oy];
 #pragma unroll
-  for (int k = 0; k < nb; ++k) {
-    const T ea = Num<T>::exp2((a[k] - amax) * Num<T>::kLog2e);
-    const T eb = Num<T>::exp2((a[nb + k] - bmax) * Num<T>::kLog2e);
-    a[k] = ea;
-    a[nb + k] = eb;
-    sa += ea;
-    sb += eb;
+    for (int k = 1; k < nb; ++k) bmax = Num<T>::max(bmax, a[cm.oy + k]);
+    sb = T(0);
+#pragma unroll
+    for (int k = 0; k < nb; ++k) {
+      const T e = Num<T>::exp2((a[cm.oy + k] - bmax) * Num<T>::kLog2e);
+      a[cm.oy + k] = e;
+      sb += e;
+    }
   }
   const T wx = W / sa, wy = H / sb;
   Site<T> s;
   T cx = xlo, cy = ylo;
-  s.x0 = xlo; s.y0 = ylo; s.bw = a[0] * wx; s.bh = a[nb] * wy;
-  s.c0 = a[2 * nb]; s.c1 = a[2 * nb + 1]; s.j = 0;
-  cx += s.bw; cy += s.bh;
+  s.x0 = xlo; s.y0 = ylo;
+  s.bw = fx ? fx[1] - fx[0] : a[cm.ox] * wx;
+  s.bh = fy ? fy[1] - fy[0] : a[cm.oy] * wy;
+  s.c0 = a[cm.od]; s.c1 = a[cm.od + 1]; s.j = 0;
+  cx = fx ? fx[1] : cx + s.bw;
+  cy = fy ? fy[1] : cy + s.bh;
 #pragma unroll
   for (int k = 1; k < nb; ++k) {
-    const T wk = a[k] * wx, hk = a[nb + k] * wy;
+    const T wk = fx ? fx[k + 1] - fx[k] : a[cm.ox + k] * wx;
+    const T hk = fy ? fy[k + 1] - fy[k] : a[cm.oy + k] * wy;
     const bool sel = (ON_Y ? cy : cx) < v;   // knot k strictly below the value
     s.x0 = sel ? cx : s.x0;
     s.y0 = sel ? cy : s.y0;
     s.bw = sel ? wk : s.bw;
     s.bh = sel ? hk : s.bh;
-    s.c0 = sel ? a[2 * nb + k] : s.c0;
-    s.c1 = sel ? a[2 * nb + k + 1] : s.c1;
+    s.c0 = sel ? a[cm.od + k] : s.c0;
+    s.c1 = sel ? a[cm.od + k + 1] : s.c1;
     s.j = sel ? k : s.j;
-    cx += wk; cy += hk;
+    cx = fx ? fx[k + 1] : cx + wk;
+    cy = fy ? fy[k + 1] : cy + hk;
   }
   s.xe = cx; s.ye = cy;   // last knot as accumulated (the reference's cumsum end)
   return s;
@@ -119,7 +150,7 @@ __device__ __forceinline__ void rqs_site(Col &a, const RqsArgs &A, T v, T &val, 
   const bool refl_r = (A.er == NF_EXTRAP_ANTI) && (v > in_hi);
   v = refl_l ? T(2) * in_lo - v : (refl_r ? T(2) * in_hi - v : v);
   T sa, sb;
-  const Site<T> s = scan_bins<T, MT, INV>(a, A.m, v, xlo, W, ylo, H, sa, sb);
+  const Site<T> s = scan_bins<T, MT, INV>(a, A, v, xlo, W, ylo, H, sa, sb);
   const bool tail_l = (A.el == NF_EXTRAP_LINEAR) && !(in_lo < v);
   const bool tail_r = (A.er == NF_EXTRAP_LINEAR) && ((INV ? s.ye : s.xe) < v);
   const T d0 = softplus2(s.c0), d1 = softplus2(s.c1);
@@ -169,7 +200,7 @@ __device__ __forceinline__ T rqs_site_vjp(Col &a, const RqsArgs &A, T x, T gout,
   const T sgn = (refl_l || refl_r) ? T(-1) : T(1);
   const T v = refl_l ? T(2) * xlo - x : (refl_r ? T(2) * (xlo + W) - x : x);
   T sa, sb;
-  const Site<T> s = scan_bins<T, MT, false>(a, A.m, v, xlo, W, ylo, H, sa, sb);
+  const Site<T> s = scan_bins<T, MT, false>(a, A, v, xlo, W, ylo, H, sa, sb);
   const bool tail_l = (A.el == NF_EXTRAP_LINEAR) && !(xlo < v);
   const bool tail_r = (A.er == NF_EXTRAP_LINEAR) && (s.xe < v);
   const bool tail = tail_l || tail_r;
@@ -221,20 +252,30 @@ __device__ __forceinline__ T rqs_site_vjp(Col &a, const RqsArgs &A, T x, T gout,
     x0b = -thb * ibw;
     wb = -(thb * th + slb * sl) * ibw;
   }
-  // back through softmax / cumsum (a[] holds the softmax numerators)
-  const T Sx = x0b * (s.x0 - xlo) + wb * s.bw;
-  const T Sy = y0b * (s.y0 - ylo) + hb * s.bh;
-  const T isa = T(1) / sa, isb = T(1) / sb;
+  // back through softmax / cumsum (the free x / y blocks of a[] hold the softmax numerators)
+  const bool fixx = MT == 0 && A.fx != nullptr, fixy = MT == 0 && A.fy != nullptr;
+  const ChanMap cm = chan_map(m, fixx, fixy);
   const T gc0 = d0b * sg0, gc1 = d1b * sg1;
+  if (!fixx) {
+    const T Sx = x0b * (s.x0 - xlo) + wb * s.bw;
+    const T isa = T(1) / sa;
 #pragma unroll
-  for (int k = 0; k < nb; ++k) {
-    const T lead_x = (k < s.j) ? x0b : ((k == s.j) ? wb : T(0));
-    const T lead_y = (k < s.j) ? y0b : ((k == s.j) ? hb : T(0));
-    a[k] = a[k] * isa * (W * lead_x - Sx);
-    a[nb + k] = a[nb + k] * isb * (H * lead_y - Sy);
+    for (int k = 0; k < nb; ++k) {
+      const T lead_x = (k < s.j) ? x0b : ((k == s.j) ? wb : T(0));
+      a[cm.ox + k] = a[cm.ox + k] * isa * (W * lead_x - Sx);
+    }
+  }
+  if (!fixy) {
+    const T Sy = y0b * (s.y0 - ylo) + hb * s.bh;
+    const T isb = T(1) / sb;
+#pragma unroll
+    for (int k = 0; k < nb; ++k) {
+      const T lead_y = (k < s.j) ? y0b : ((k == s.j) ? hb : T(0));
+      a[cm.oy + k] = a[cm.oy + k] * isb * (H * lead_y - Sy);
+    }
   }
 #pragma unroll
-  for (int k = 0; k < m; ++k) a[2 * nb + k] = (k == s.j) ? gc0 : ((k == s.j + 1) ? gc1 : T(0));
+  for (int k = 0; k < m; ++k) a[cm.od + k] = (k == s.j) ? gc0 : ((k == s.j + 1) ? gc1 : T(0));
   return grad_in;
 }
 
@@ -247,7 +288,7 @@ __global__ __launch_bounds__(kBlock) void rqs_kernel(RqsArgs A) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   __shared__ double red[kBlock / kWave];
   const int b = blockIdx.y;
-  const int C_rt = 3 * A.m - 2;
+  const int C_rt = A.C;
   const T *__restrict__ xin = static_cast<const T *>(A.x) + int64_t(b) * A.x_bs;
   const T *__restrict__ par = static_cast<const T *>(A.params) + int64_t(b) * A.p_bs;
   T *__restrict__ yout = static_cast<T *>(A.y) + int64_t(b) * A.y_bs;
@@ -301,7 +342,7 @@ __global__ __launch_bounds__(kBlock) void rqs_vjp_kernel(RqsArgs A) {
   constexpr int C = MT > 0 ? 3 * MT - 2 : 1;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int b = blockIdx.y;
-  const int C_rt = 3 * A.m - 2;
+  const int C_rt = A.C;
   const T *__restrict__ xin = static_cast<const T *>(A.x) + int64_t(b) * A.x_bs;
   const T *__restrict__ par = static_cast<const T *>(A.params) + int64_t(b) * A.p_bs;
   const T *__restrict__ gout = static_cast<const T *>(A.grad_out) + int64_t(b) * A.y_bs;
@@ -369,8 +410,6 @@ static int fill_args(RqsArgs &A, int64_t B, int64_t V, const nf_rqs_opts *o, con
   NF_REQUIRE(B >= 0 && V >= 0, "nf_rqs: negative size");
   NF_REQUIRE(B <= 65535, "nf_rqs: batch %lld > 65535 (split the batch)", (long long)B);
   NF_REQUIRE(o->m >= 2, "nf_rqs: knots_len m=%d < 2", o->m);
-  NF_REQUIRE(o->fixed_knots_x == nullptr && o->fixed_knots_y == nullptr,
-             "nf_rqs: fixed knots_x / knots_y are not supported by this build");
   NF_REQUIRE(o->xhi > o->xlo && o->yhi > o->ylo, "nf_rqs: empty xlim/ylim");
   for (int e : {o->extrap_left, o->extrap_right})
     NF_REQUIRE(e == NF_EXTRAP_NONE || e == NF_EXTRAP_LINEAR || e == NF_EXTRAP_ANTI,
@@ -380,7 +419,8 @@ static int fill_args(RqsArgs &A, int64_t B, int64_t V, const nf_rqs_opts *o, con
     NF_REQUIRE(V % 2 == 0, "nf_rqs: pair layout needs even V");
     NF_REQUIRE(!st || (st->x_batch % 2 == 0 && st->y_batch % 2 == 0), "nf_rqs: pair layout needs even batch strides");
   }
-  const int C = 3 * o->m - 2;
+  const int C = (o->fixed_knots_x ? 0 : o->m - 1) + (o->fixed_knots_y ? 0 : o->m - 1) + o->m;
+  A.fx = o->fixed_knots_x; A.fy = o->fixed_knots_y; A.C = C;
   A.mask = mask;
   A.V = V;
   A.Vp = o->layout == NF_LAYOUT_PAIR ? V / 2 : V;
@@ -407,9 +447,9 @@ static bool has_static_kernel(int m) {
 // Workgroup size: 256 for the register kernels; the LDS-column kernel keeps one column of
 // C logits per lane, so it shrinks the workgroup until the tile fits 64 KiB and opts in to
 // the CU's full 160 KiB only for very long splines.  Returns 0 if even 64 lanes do not fit.
-template <typename T> static int pick_block(int m) {
-  if (has_static_kernel(m)) return kBlock;
-  const size_t col = size_t(3 * m - 2) * sizeof(T);
+template <typename T> static int pick_block(const RqsArgs &A) {
+  if (has_static_kernel(A.m) && !A.fx && !A.fy) return kBlock;
+  const size_t col = size_t(A.C) * sizeof(T);
   int block = kBlock;
   while (block > kWave && col * block > 64 * 1024) block >>= 1;
   return col * block <= 160 * 1024 ? block : 0;
@@ -419,7 +459,7 @@ template <typename T, int MODE, bool VJP>
 static int dispatch(const RqsArgs &A, dim3 grid, int block, hipStream_t stream) {
   const bool pair = A.layout == NF_LAYOUT_PAIR;
 #define NF_CASE(MV)                                                                         \
-  if (A.m == MV) {                                                                          \
+  if (A.m == MV && !A.fx && !A.fy) {                                                                          \
     if (VJP) {                                                                              \
       if (pair) hipLaunchKernelGGL((rqs_vjp_kernel<T, MV, MODE, true>), grid, dim3(kBlock), 0, stream, A);  \
       else hipLaunchKernelGGL((rqs_vjp_kernel<T, MV, MODE, false>), grid, dim3(kBlock), 0, stream, A);      \
@@ -431,7 +471,7 @@ static int dispatch(const RqsArgs &A, dim3 grid, int block, hipStream_t stream) 
   }
   NF_STATIC_M(NF_CASE)
 #undef NF_CASE
-  const size_t lds = size_t(3 * A.m - 2) * sizeof(T) * block;
+  const size_t lds = size_t(A.C) * sizeof(T) * block;
 #define NF_LDS_LAUNCH(KERNEL)                                                                     \
   do {                                                                                            \
     if (lds > 64 * 1024)                                                                          \
@@ -459,7 +499,7 @@ static int run_map(const void *in, const void *params, const uint8_t *mask, cons
   if (rc) return rc;
   NF_REQUIRE(in && params && out && logj, "nf_rqs: NULL tensor pointer");
   if (B == 0) return NF_OK;
-  const int block = pick_block<T>(A.m);
+  const int block = pick_block<T>(A);
   NF_REQUIRE(block > 0, "nf_rqs: knots_len m=%d does not fit the 160 KiB of LDS of one CU", A.m);
   const Tiling t = make_tiling(A.units, B, block);
   NF_REQUIRE(t.blocks_x <= kMaxBlocksX, "nf_rqs: lattice too large for one launch");
@@ -486,7 +526,7 @@ static int run_vjp(const void *x, const void *params, const uint8_t *mask, const
   if (rc) return rc;
   NF_REQUIRE(x && params && grad_out && grad_logj && grad_in && grad_params, "nf_rqs_vjp: NULL tensor pointer");
   if (B == 0 || A.units == 0) return NF_OK;
-  const int block = pick_block<T>(A.m);
+  const int block = pick_block<T>(A);
   NF_REQUIRE(block > 0, "nf_rqs: knots_len m=%d does not fit the 160 KiB of LDS of one CU", A.m);
   const Tiling t = make_tiling(A.units, B, block);
   A.x = x; A.params = params; A.grad_out = grad_out; A.grad_logj = grad_logj;

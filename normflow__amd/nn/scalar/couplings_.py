@@ -185,16 +185,32 @@ class RQSplineCoupling_(Coupling_):
         self.knots_y = knots_y
         self.extrap = extrap
 
-    def _opts(self, n_channels, layout):
-        if self.knots_x is not None or self.knots_y is not None:
-            raise NotImplementedError("fixed knots_x / knots_y are not supported by the HIP kernels yet")
-        if (n_channels + 2) % 3:
-            raise Exception(f"net output has {n_channels} channels; 3m-2 are needed for m knots")
-        return _hip.make_rqs_opts((n_channels + 2) // 3, self.xlim, self.ylim, self.extrap, layout)
+    def _fixed(self, knots, like):
+        """A fixed 1-D knot vector as a contiguous device tensor of the field's dtype."""
+        if knots is None:
+            return None
+        k = torch.as_tensor(knots)
+        if k.dim() != 1:
+            raise NotImplementedError("only 1-D fixed knots_x / knots_y are supported")
+        return k.detach().to(device=like.device, dtype=like.dtype).contiguous()
+
+    def _opts(self, n_channels, layout, like):
+        """knots_len m from the channel count: 3m-2 (free), 2m-1 (x or y fixed), m (both fixed)
+        (couplings_.py:236-256)."""
+        kx, ky = self._fixed(self.knots_x, like), self._fixed(self.knots_y, like)
+        n_fixed = (kx is not None) + (ky is not None)
+        div = 3 - n_fixed
+        if (n_channels + 2 - n_fixed) % div:
+            raise Exception(f"net output has {n_channels} channels; {div}m-{2 - n_fixed} are needed for m knots")
+        m = (n_channels + 2 - n_fixed) // div
+        for k in (kx, ky):
+            if k is not None and k.numel() != m:
+                raise Exception(f"fixed knots have {k.numel()} entries but the net output implies m={m}")
+        return _hip.make_rqs_opts(m, self.xlim, self.ylim, self.extrap, layout, kx, ky)
 
     def _atom(self, inverse, *, x_active, x_frozen, parity, net, log0=0):
         def kernel(v, params, l0, act, layout):
-            return _hip.RQSCouplingFn.apply(v, params, l0, act, self._opts(params.shape[1], layout), inverse)
+            return _hip.RQSCouplingFn.apply(v, params, l0, act, self._opts(params.shape[1], layout, v), inverse)
         return self._run_atom(kernel, x_active, x_frozen, parity, net, log0, 46)
 
     def atomic_forward(self, **kw):

@@ -64,8 +64,6 @@ def layouts_for(shape):
 def test_atoms_against_reference_goldens(golden, tag, dtype):
     z = golden("atoms")
     kind = tag.split("/")[0]
-    if kind == "rqs_fixedx":
-        pytest.skip("fixed knots_x: not supported by the kernels yet (raises NotImplementedError)")
     tol = TOL[dtype]
     shape, parity = tuple(int(v) for v in z[f"{tag}/shape"]), int(z[f"{tag}/parity"])
     act = O.channel_mask(shape, parity).to(torch.uint8).reshape(-1).to(DEV)
@@ -89,9 +87,12 @@ def test_atoms_against_reference_goldens(golden, tag, dtype):
                 opts = [_hip.make_rqs_opts(4, o["xlims"][i], o["ylims"][i], o["extraps"][i], lay) for i in range(2)]
                 return _hip.MultiRQSCouplingFn.apply(inp, params, log0, act, opts, inverse)
             o = ATOM_OPTS[kind]
-            m = (params.shape[1] + 2) // 3
-            return _hip.RQSCouplingFn.apply(inp, params, log0, act,
-                                            _hip.make_rqs_opts(m, o["xlim"], o["ylim"], o["extrap"], lay), inverse)
+            if kind == "rqs_fixedx":      # knots_x fixed: 2m-1 channels
+                kx = g("knots_x").contiguous()
+                opts = _hip.make_rqs_opts((params.shape[1] + 1) // 2, o["xlim"], o["ylim"], o["extrap"], lay, kx)
+            else:
+                opts = _hip.make_rqs_opts((params.shape[1] + 2) // 3, o["xlim"], o["ylim"], o["extrap"], lay)
+            return _hip.RQSCouplingFn.apply(inp, params, log0, act, opts, inverse)
 
         # The rqs_lin goldens put every 3rd input EXACTLY on a knot (tie semantics of the bin
         # search) and draw wide logits (std 1.2 => bins down to ~1e-2 of the range):
@@ -136,7 +137,9 @@ def test_atoms_against_reference_goldens(golden, tag, dtype):
             fn = {"affine": O.affine_coupling_atom, "shift": O.shift_coupling_atom}.get(kind, O.rqs_coupling_atom)
             yo = T(z[f"{tag}/y"], dev="cpu").clone().requires_grad_(True)
             oo = T(z[f"{tag}/out"], dev="cpu").clone().requires_grad_(True)
-            opts = ATOM_OPTS.get(kind, {})
+            opts = dict(ATOM_OPTS.get(kind, {}))
+            if kind == "rqs_fixedx":
+                opts["knots_x"] = T(z[f"{tag}/knots_x"], dev="cpu")
             xo, lo = fn(yo, oo, O.channel_mask(shape, parity), inverse=True, log0=T(z[f"{tag}/logJ"], dev="cpu"), **opts)
             go_y, go_p = torch.autograd.grad(lo.mean() + (xo ** 2).mean(), (yo, oo), allow_unused=True)
             go_p = torch.zeros_like(oo) if go_p is None else go_p
@@ -502,3 +505,30 @@ def test_convact_fused_matches_torch_path_and_grads():
                                   extrap={'left': 'linear', 'right': 'linear'}).to(DEV)
         y2, l2 = cpl64(xf.double())
     assert rel(y1, y2) <= 1e-5 and rel(l1, l2) <= 1e-5
+
+
+def test_fixed_knots_module_level_vs_oracle():
+    """RQSplineCoupling_(knots_x=..., knots_y=...) variants (couplings_.py:236-256): x fixed,
+    y fixed, both fixed -- module API against the oracle, fp64 and fp32, forward + inverse."""
+    torch.manual_seed(9)
+    shape, B, m = (6, 4), 4, 5
+    kx = torch.tensor([-2.0, -0.7, 0.1, 0.9, 2.0], dtype=torch.float64, device='cpu')
+    ky = torch.tensor([-2.0, -1.1, -0.2, 1.2, 2.0], dtype=torch.float64, device='cpu')
+    for fx, fy, C in ((kx, None, 2 * m - 1), (None, ky, 2 * m - 1), (kx, ky, m)):
+        for dtype in (torch.float64, torch.float32):
+            net = ConvAct(1, C, 3, conv_dim=2, hidden_sizes=[4], acts=['tanh', None]).to(DEV, dtype)
+            mask = EvenOddMask(shape=shape)
+            cpl = RQSplineCoupling_([net], mask=mask, xlim=(-2.0, 2.0), ylim=(-2.0, 2.0), knots_x=fx, knots_y=fy,
+                                    extrap={'left': 'linear', 'right': 'linear'}).to(DEV)
+            x = 1.5 * torch.randn((B,) + shape, device=DEV, dtype=dtype)
+            with torch.no_grad():
+                y, lj = cpl(x)
+                xb, lb = cpl.backward(y, lj)
+                convs = [mod for mod in net if hasattr(mod, 'weight')]
+                layers = [(c.weight.double().cpu(), c.bias.double().cpu()) for c in convs]
+                yo, lo = O.coupling_block(x.double().cpu(), [lambda t: O.conv_act(t, layers, ['tanh', None])], 'rqs',
+                                          shape, xlim=(-2.0, 2.0), ylim=(-2.0, 2.0), knots_x=fx, knots_y=fy,
+                                          extrap={'left': 'linear', 'right': 'linear'})
+            tol = 1e-9 if dtype == torch.float64 else 2e-5
+            assert rel(y, yo) <= tol and rel(lj, lo) <= tol
+            assert rel(xb, x) <= 100 * tol and float(lb.abs().max()) <= 100 * tol
