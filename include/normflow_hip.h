@@ -171,9 +171,12 @@ int nf_distconv_vjp(const void *v, const void *knots, int K, const void *grad_ou
  * axes of extent 1 and kernel extent 1.
  *
  *   in      (B, cin, V) f32, channel planes (the layout of a torch (B, C, *L) tensor)
- *   wfrag   weights in MFMA-fragment order: [tap][ceil(cin/4)][ceil(cout/16)][4][16] with
- *           wfrag[t][q][n][g][j] = W[16n + j][4q + g][t] (0 where out of range), taps in
- *           row-major kernel order
+ *   wfrag   weights in MFMA-fragment order.  cin % 4 == 0:
+ *           [tap][cin/4][ceil(cout/16)][4][16], wfrag[t][q][n][g][j] = W[16n + j][4q + g][t];
+ *           otherwise K-packed: [step][ceil(cout/16)][4][16] with
+ *           wfrag[s][n][g][j] = W[16n + j][kk % cin][kk / cin], kk = 4s + g, for
+ *           s < nf_conv_packed_steps(cin, ntaps); 0 where out of range; taps in row-major
+ *           kernel order
  *   bias    (cout) or NULL
  *   out     (B, cout, V), or with compact != 0 (B, cout, V/2): only the site of every
  *           aligned pair (2h, 2h+1) whose coordinate sum has parity `active_parity`
@@ -182,6 +185,7 @@ int nf_distconv_vjp(const void *v, const void *knots, int K, const void *grad_ou
  */
 int nf_conv_cin_pad(int cin);
 int nf_conv_ntiles(int cout);
+int nf_conv_packed_steps(int cin, int ntaps);
 int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, void *out, int64_t B,
                 const int32_t *lattice, const int32_t *ksize, int cin, int cout, int act,
                 int compact, int active_parity, int dtype, void *stream);

@@ -52,6 +52,7 @@ PROTOTYPES = {
     "nf_distconv_vjp": (_I, [_P, _P, _I, _P, _P, _P, _P, _I64, _I64, _I, _I, _P, _SZ, _I, _P]),
     "nf_conv_cin_pad": (_I, [_I]),
     "nf_conv_ntiles": (_I, [_I]),
+    "nf_conv_packed_steps": (_I, [_I, _I]),
     "nf_conv_fwd": (_I, [_P, _P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I, _I, _I,
                          _I, _P]),
 }
@@ -376,7 +377,13 @@ def pack_conv_weight(w):
     ntaps = 1
     for k in w.shape[2:]:
         ntaps *= k
-    cin_pad, nt = (cin + 3) // 4 * 4, (cout + 15) // 16
+    nt = (cout + 15) // 16
+    ns = load().nf_conv_packed_steps(cin, ntaps)
+    if ns:      # cin % 4 != 0: K = (tap, ci) flattened, 4 per step
+        wk = w.new_zeros(nt * 16, 4 * ns)
+        wk[:cout, :cin * ntaps] = w.reshape(cout, cin, ntaps).permute(0, 2, 1).reshape(cout, ntaps * cin)
+        return wk.reshape(nt, 16, ns, 4).permute(2, 0, 3, 1).contiguous()
+    cin_pad = (cin + 3) // 4 * 4
     wp = w.new_zeros(nt * 16, cin_pad, ntaps)
     wp[:cout, :cin] = w.reshape(cout, cin, ntaps)
     return wp.reshape(nt, 16, cin_pad // 4, 4, ntaps).permute(4, 2, 0, 3, 1).contiguous()

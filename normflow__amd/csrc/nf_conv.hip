@@ -43,6 +43,7 @@ struct ConvArgs {
   int S;                // LDS plane stride (dwords)
   int cin, cin_pad, cout, kq, nt_total, nt0;
   int act, compact, parity;
+  int packed, ns;       // packed: K = (tap, ci) flattened, 4 per step, ns steps (multiple of 4)
   int dbg;              // profiling ablation (NF_CONV_DBG): bit0 skip staging, bit1 skip the MFMA loop
 };
 
@@ -151,6 +152,55 @@ __device__ __forceinline__ void mma_taps(const ConvArgs &A, const float *tile, c
   }
 }
 
+// K-packed variant for cin % 4 != 0 (e.g. the 1 -> 8 first layer of ConvAct): the reduction
+// index kk = tap * cin + ci is cut into steps of 4 regardless of tap boundaries, so no MFMA
+// k-slot is wasted on channel padding.  The k-group g of a lane then needs its OWN LDS offset
+// per step; the offsets live in a small LDS table koff[g][step] (built once per workgroup) and
+// are fetched four steps at a time with one ds_read_b128.
+template <int MT, int NT>
+__device__ __forceinline__ void mma_packed(const ConvArgs &A, const float *tile, const int *koff,
+                                           const int (&abase)[MT], const float *__restrict__ wf,
+                                           f32x4 (&acc)[MT][NT]) {
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const int wstep = A.nt_total << 6;
+  const int ngroups = A.ns >> 2;
+  float a0[4][MT], b0[4][NT], a1[4][MT], b1[4][NT];
+  auto request = [&](float (&a)[4][MT], float (&b)[4][NT], int grp) {
+    const i32x4 off = *reinterpret_cast<const i32x4 *>(koff + (grp << 2));
+    const float *__restrict__ wt = wf + int64_t(grp) * (4 * wstep);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[i][nt] = wt[i * wstep + (nt << 6)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[i][mt] = tile[abase[mt] + off[i]];
+  };
+  auto multiply = [&](const float (&a)[4][MT], const float (&b)[4][NT]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][mt], b[i][nt], acc[mt][nt], 0, 0, 0);
+  };
+  request(a0, b0, 0);
+  for (int grp = 0; grp < ngroups; grp += 2) {
+    request(a1, b1, grp + 1 < ngroups ? grp + 1 : grp);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp + 1 < ngroups) {
+      request(a0, b0, grp + 2 < ngroups ? grp + 2 : grp + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 template <int MT, int NT, bool COMPACT>
 __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
   extern __shared__ __align__(16) float tile[];
@@ -189,6 +239,25 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
       rowdst[t] = t * h3;
     }
     for (int i = threadIdx.x; i < (A.cin_pad - A.cin) * A.S; i += kBlock) tile[A.cin * A.S + i] = 0.f;
+    if (A.packed) {                                     // koff[g][step], see mma_packed
+      int *koff = reinterpret_cast<int *>(tile) + ((A.cin_pad * A.S + 2 * R + 3) & ~3);   // 16-B aligned
+      const int ktot = A.k[0] * A.k[1] * A.k[2] * A.k[3] * A.cin;
+      for (int t = threadIdx.x; t < 4 * A.ns; t += kBlock) {
+        const int gq = t / A.ns, st = t - gq * A.ns;
+        const int kk = 4 * st + gq;
+        int off = 0;
+        if (kk < ktot) {
+          int tap = kk / A.cin;
+          const int ci = kk - tap * A.cin;
+          const int j3 = tap % A.k[3]; tap /= A.k[3];
+          const int j2 = tap % A.k[2]; tap /= A.k[2];
+          const int j1 = tap % A.k[1];
+          const int j0 = tap / A.k[1];
+          off = ((j0 * h1 + j1) * h2 + j2) * h3 + j3 + ci * A.S;
+        }
+        koff[t] = off;
+      }
+    }
     __syncthreads();
     for (int z3b = 0; z3b < h3; z3b += kWave) {         // 64-wide chunks of the fastest axis
       const int z3 = z3b + lane;
@@ -228,7 +297,7 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
     const int z0 = u;
     int z3 = p3;
     if (COMPACT) z3 = 2 * p3 + ((A.parity + o[0] + z0 + o[1] + z1 + o[2] + z2) & 1);
-    abase[mt] = ((z0 * h1 + z1) * h2 + z2) * h3 + z3 + g * A.S;
+    abase[mt] = ((z0 * h1 + z1) * h2 + z2) * h3 + z3 + (A.packed ? 0 : g * A.S);
   }
 
   f32x4 acc[MT][NT];
@@ -242,7 +311,10 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
   // unrolled twice over two named fragment buffers so that no register rotation (and hence no
   // early s_waitcnt) sits between a request and its use one tap later.
   const float *__restrict__ wf = A.wfrag + (int64_t(A.nt0) << 6) + lane;
-  if (!(A.dbg & 2)) {
+  if (A.packed) {
+    if (!(A.dbg & 2)) mma_packed<MT, NT>(A, tile, reinterpret_cast<const int *>(tile) + ((A.cin_pad * A.S + 2 * R + 3) & ~3) + g * A.ns,
+                                          abase, wf, acc);
+  } else if (!(A.dbg & 2)) {
     switch (A.kq) {
       case 1: mma_taps<MT, NT, 1>(A, tile, abase, wf, acc); break;
       case 2: mma_taps<MT, NT, 2>(A, tile, abase, wf, acc); break;
@@ -317,6 +389,11 @@ static void launch(const ConvArgs &A, dim3 grid, size_t lds, hipStream_t stream)
 using namespace nf;
 
 extern "C" int nf_conv_cin_pad(int cin) { return (cin + 3) & ~3; }
+// number of 4-wide reduction steps of the K-packed weight layout (cin % 4 != 0), 0 otherwise
+extern "C" int nf_conv_packed_steps(int cin, int ntaps) {
+  if (cin % 4 == 0) return 0;
+  return ((((cin * ntaps + 3) / 4) + 3) / 4) * 4;
+}
 extern "C" int nf_conv_ntiles(int cout) { return (cout + 15) >> 4; }
 
 extern "C" int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, void *out, int64_t B,
@@ -346,6 +423,13 @@ extern "C" int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, 
   A.cin = cin; A.cin_pad = (cin + 3) & ~3; A.cout = cout; A.kq = A.cin_pad / 4;
   A.nt_total = (cout + 15) >> 4;
   A.act = act; A.compact = compact ? 1 : 0; A.parity = active_parity & 1;
+  A.packed = (cin % 4) != 0;
+  if (A.packed) {
+    const int ktot = cin * ksize[0] * ksize[1] * ksize[2] * ksize[3];
+    A.ns = ((((ktot + 3) / 4) + 3) / 4) * 4;   // steps of 4 k, rounded up to groups of 4 steps
+    A.cin_pad = cin;                           // no channel padding in this mode
+    A.kq = 0;
+  }
   {
     static const int dbg = getenv("NF_CONV_DBG") ? atoi(getenv("NF_CONV_DBG")) : 0;
     A.dbg = dbg;
@@ -355,14 +439,17 @@ extern "C" int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, 
   // the fastest axis (coalescing), then as cubic as the lattice allows (least halo).  MT = 4
   // unless the staged box would then exceed ~80 KiB of LDS (two workgroups per CU keep one
   // staging while the other multiplies); then MT = 2.
-  int MT = 4;
+  static const int lds_cap_kb = getenv("NF_CONV_LDS_KB") ? atoi(getenv("NF_CONV_LDS_KB")) : 78;
+  static const int box3_cap = getenv("NF_CONV_BOX3") ? atoi(getenv("NF_CONV_BOX3")) : 32;
+  static const int mt_first = getenv("NF_CONV_MT") ? atoi(getenv("NF_CONV_MT")) : 4;
+  int MT = mt_first == 2 ? 2 : 4;
   int box[4];
   for (int attempt = 0; attempt < 2; ++attempt) {
     const int units = (kBlock / kWave) * MT * 16;
     const int target = compact ? 2 * units : units;        // sites in the box
     int cap[4];
     for (int mu = 0; mu < 4; ++mu) { cap[mu] = 1 << ilog2(A.L[mu]); box[mu] = 1; }
-    box[3] = cap[3] < 32 ? cap[3] : 32;
+    box[3] = cap[3] < box3_cap ? cap[3] : box3_cap;
     const int min3 = compact ? 8 : 4;                       // >= 4 units along the fastest axis
     if (box[3] < min3) box[3] = min3;
     int vol = box[3];
@@ -386,7 +473,7 @@ extern "C" int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, 
     }
     int64_t hv = 1;
     for (int mu = 0; mu < 4; ++mu) hv *= box[mu] + A.k[mu] - 1;
-    if (MT == 2 || hv * ((cin + 3) & ~3) * 4 <= 78 * 1024) break;
+    if (MT == 2 || hv * ((cin + 3) & ~3) * 4 <= int64_t(lds_cap_kb) * 1024) break;
     MT = 2;
   }
   int64_t nblocks = 1;
@@ -407,7 +494,8 @@ extern "C" int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, 
   int64_t rows = 1;
   for (int mu = 0; mu < 3; ++mu) rows *= A.hal[mu];
   NF_REQUIRE(V < (int64_t(1) << 31), "nf_conv_fwd: lattice volume must be < 2^31");
-  const size_t lds = size_t(A.cin_pad) * S * sizeof(float) + size_t(rows) * 2 * sizeof(int);
+  const size_t lds = size_t(A.cin_pad) * S * sizeof(float) + size_t(rows) * 2 * sizeof(int) +
+                     (A.packed ? size_t(4) * A.ns * sizeof(int) + 16 : 0);
   NF_REQUIRE(lds <= 160 * 1024, "nf_conv_fwd: input box needs %zu B of LDS (> 160 KiB): cin=%d, kernel %dx%dx%dx%d",
              lds, cin, A.k[0], A.k[1], A.k[2], A.k[3]);
   NF_REQUIRE(nblocks <= 0x7fffffff, "nf_conv_fwd: lattice too large");

@@ -251,6 +251,8 @@ def rqs_coupling_atom(x_active, out, active_mask, *, xlim=(0, 1), ylim=(0, 1),
     kx, ky, kd = knots_from_logits(out, xlim, ylim, knots_x, knots_y)
     ref = out
     kx, ky, kd = (_bcast_like(k, ref) for k in (kx, ky, kd))
+    full = (out.shape[0], kd.shape[1]) + tuple(out.shape[2:])      # fixed 1-D knots broadcast to every site
+    kx, ky, kd = (k.expand(full) for k in (kx, ky, kd))
     kx, ky, kd = augment_knots(kx, ky, kd, axis=1, **extrap)
     v = x_active.unsqueeze(1)
     f = rqs_invert if inverse else rqs_evaluate
