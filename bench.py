@@ -28,6 +28,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak (= vector f32 peak)
 
 
 def parse():
@@ -96,6 +97,38 @@ def time_rqs_kernel(cpl, lattice, m, dev, reps, layout_pair):
     sec = e0.elapsed_time(e1) * 1e-3 / reps
     algo_bytes = slab * (V // 2) * (C + 2) * 4          # B*(V/2)*(C+2)*sizeof
     return dict(seconds=sec, slab=slab, algo_bytes=algo_bytes, gbs=algo_bytes / sec / 1e9)
+
+
+def time_fused_last_layer(cpl, lattice, m, dev, reps):
+    """Average duration of one nf_conv_rqs launch (last conv layer 8 -> 3m-2 at the active sites
+    + fused RQ-spline epilogue) on the slab shape the pipeline uses; HIP events on the launch
+    stream.  Algorithmic flops: 2 * 3^d * cin * cout per ACTIVE site (last layer)."""
+    from normflow__amd import _hip
+    V = 1
+    for n in lattice:
+        V *= n
+    net = cpl.nets[0]
+    hidden = max(net.conv_kwargs['hidden_sizes'])
+    slab = max(1, min(64, cpl.HIDDEN_SLAB_BYTES // (hidden * V * 4)))
+    last = [mod for mod in net if any(True for _ in mod.parameters())][-1]
+    g = torch.Generator(device=dev).manual_seed(98)
+    h = torch.tanh(torch.randn((slab, hidden) + tuple(lattice), device=dev, dtype=torch.float32, generator=g))
+    x = torch.randn(slab, V, device=dev, dtype=torch.float32, generator=g)
+    opts = _hip.make_rqs_opts(m, (-5.0, 5.0), (-5.0, 5.0), {'left': 'linear', 'right': 'linear'}, _hip.LAYOUT_PAIR)
+    w, b = last.weight.detach(), last.bias.detach()
+    f = lambda: _hip.conv_rqs(h, w, b, x, None, 0, opts, False)
+    for _ in range(2):
+        f()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    flops = 2.0 * (3 ** len(lattice)) * hidden * (3 * m - 2) * (V // 2) * slab
+    return dict(seconds=sec, slab=slab, flops=flops, tflops=flops / sec / 1e12)
 
 
 def cpu_baseline(cpl, lattice, m, budget_s):
@@ -181,15 +214,17 @@ def main():
     assert bool(torch.isfinite(logJ).all()) and bool(torch.isfinite(y).all())
 
     if rank == 0:
-        # the layout the timed pipeline feeds the coupling kernel with (pair-compact when the
-        # parameter net is this package's ConvAct on a plain even-odd mask)
+        # Which kernels the timed pipeline runs: with this package's ConvAct on a plain even-odd
+        # mask the last conv layer and the spline are ONE kernel (nf_conv_rqs); otherwise the
+        # stand-alone coupling kernel consumes a materialised logit tensor.
         with torch.no_grad():
             probe = torch.zeros((1,) + lattice, device=dev, dtype=torch.float32)
+            fused = cpl._fused_atom(False, probe, probe, 0, cpl.nets[0], 0) is not None
             pipeline_pair = cpl._params(cpl.nets[0], probe, parity=0)[1] == 1
         kt = time_rqs_kernel(cpl, lattice, a.knots, dev, a.kernel_reps, pipeline_pair)
-        kt_pair = time_rqs_kernel(cpl, lattice, a.knots, dev, a.kernel_reps, True)
-        # HBM traffic of one launch of this kernel from the committed PMC profile (rocprofv3 cannot
-        # collect counters from inside the bench); only quoted when the launch shape is the profiled one
+        # HBM traffic of one launch of the stand-alone coupling kernel from the committed PMC
+        # profile (rocprofv3 cannot collect counters from inside the bench); only quoted when the
+        # launch shape is the profiled one
         traffic, traffic_src = None, None
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_rqs.json")))
@@ -197,6 +232,23 @@ def main():
                 traffic, traffic_src = prof["hbm_bytes_per_launch"], "profiles/r01_pmc_rqs.json"
         except (OSError, KeyError, ValueError):
             pass
+        hbm_obj = {"kernel": "nf::rqs_kernel<float,16,fwd>" + ("<pair>" if pipeline_pair else "<full>") +
+                             " (stand-alone RQ-spline coupling kernel)",
+                   "bound": "hbm", "achieved": kt["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": kt["gbs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                   "launch_ms": 1e3 * kt["seconds"], "slab_batch": kt["slab"],
+                   "algorithmic_bytes_per_launch": kt["algo_bytes"],
+                   "in_timed_pipeline": not fused}
+        if fused:
+            ft = time_fused_last_layer(cpl, lattice, a.knots, dev, a.kernel_reps)
+            roof = {"kernel": "nf::conv_kernel<2,3,compact,fused-rqs-fwd> (last conv layer 8->46 at the active sites "
+                              "+ RQ-spline coupling epilogue; dominant kernel of the timed region)",
+                    "bound": "mfma", "achieved": ft["tflops"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ft["tflops"] / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                    "launch_ms": 1e3 * ft["seconds"], "slab_batch": ft["slab"],
+                    "algorithmic_flops_per_launch": ft["flops"]}
+        else:
+            roof = hbm_obj
         cfgs = a.batch * world * a.steps
         line = {
             "metric": "lattice configs/sec (forward+logdet)", "value": cfgs / elapsed, "unit": "configs/s",
@@ -207,13 +259,8 @@ def main():
                                    f"layers (knots_len {a.knots}, ConvAct 1-8-8-{3*a.knots-2}, k=3, tanh), "
                                    f"batch {a.batch} per GPU, forward + log|det J|, no_grad",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}"},
-            "roofline": {"kernel": "nf::rqs_kernel<float,16,fwd>" + ("<pair>" if pipeline_pair else "<full>"),
-                         "bound": "hbm", "achieved": kt["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": kt["gbs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "launch_ms": 1e3 * kt["seconds"], "slab_batch": kt["slab"],
-                         "algorithmic_bytes_per_launch": kt["algo_bytes"],
-                         "pair_layout_variant": {"achieved": kt_pair["gbs"], "frac": kt_pair["gbs"] / HBM_PEAK_GBS,
-                                                 "launch_ms": 1e3 * kt_pair["seconds"]}},
+            "roofline": roof,
+            "roofline_hbm_kernel": hbm_obj,
         }
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cpl, lattice, a.knots, a.cpu_seconds)

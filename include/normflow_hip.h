@@ -190,6 +190,22 @@ int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, void *out, 
                 const int32_t *lattice, const int32_t *ksize, int cin, int cout, int act,
                 int compact, int active_parity, int dtype, void *stream);
 
+/* ---- K5+K2 fused: last conv layer of the parameter net + RQ-spline coupling ---------------
+ * The (B, 3m-2, V/2) logit tensor is produced in the MFMA accumulators, staged in LDS and
+ * consumed by the spline map in the same workgroup; it never goes to HBM (SURVEY 8(f) item 1:
+ * src/nn/scalar/modules.py:120-145 feeding src/nn/scalar/couplings_.py:178-200).
+ * Inference only (no VJP); needs a plain even-odd activity pattern (`active_parity` = parity of
+ * the coordinate sum of the active sites), an even fastest axis, knots_len in {4, 8, 16}.
+ *   in (B, cin, V) hidden activations; wfrag/bias as nf_conv_fwd with cout = 3m-2;
+ *   x_active, y (B, V); log0, logj (B); inverse != 0 applies the inverse map.
+ */
+int nf_conv_rqs_supported(int cout, int m);
+int nf_conv_rqs(const void *in, const void *wfrag, const void *bias, const void *x_active,
+                const void *log0, void *y, void *logj, int64_t B, const int32_t *lattice,
+                const int32_t *ksize, int cin, int cout, int active_parity,
+                const nf_rqs_opts *opts, int inverse, void *workspace, size_t workspace_bytes,
+                int dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

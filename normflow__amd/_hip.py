@@ -53,6 +53,9 @@ PROTOTYPES = {
     "nf_conv_cin_pad": (_I, [_I]),
     "nf_conv_ntiles": (_I, [_I]),
     "nf_conv_packed_steps": (_I, [_I, _I]),
+    "nf_conv_rqs_supported": (_I, [_I, _I]),
+    "nf_conv_rqs": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I,
+                         C.POINTER(RqsOpts), _I, _P, _SZ, _I, _P]),
     "nf_conv_fwd": (_I, [_P, _P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I, _I, _I,
                          _I, _P]),
 }
@@ -464,3 +467,30 @@ def conv_layer(x, weight, bias, act=0, compact=False, parity=0):
     x = x.contiguous()
     return _conv_launch(x, pack_conv_weight(weight.detach()), None if bias is None else bias.detach(),
                         weight.shape[2:], weight.shape[0], act, compact, parity)
+
+
+def conv_rqs(h, weight, bias, x_active, log0, parity, opts, inverse):
+    """Fused last conv layer + RQ-spline coupling (nf_conv_rqs); inference only.
+    h: (B, cin, *L) fp32 hidden activations; x_active: (B, V); returns (y (B, V), logJ (B))."""
+    _require_device(h, weight, bias, x_active, log0)
+    lib = load()
+    h, x_active = h.contiguous(), x_active.contiguous()
+    B, cin = h.shape[:2]
+    lat = list(h.shape[2:])
+    d = len(lat)
+    lat4 = (C.c_int32 * 4)(*([1] * (4 - d) + lat))
+    k4 = (C.c_int32 * 4)(*([1] * (4 - d) + list(weight.shape[2:])))
+    V = x_active.shape[1]
+    wfrag = pack_conv_weight(weight.detach())
+    bias = None if bias is None else bias.detach().contiguous()
+    y = torch.empty_like(x_active)
+    logj = torch.empty(B, dtype=x_active.dtype, device=x_active.device)
+    ws = _workspace(min(B, MAX_B), V, h.device)
+    for b0 in range(0, B, MAX_B):
+        b1 = min(B, b0 + MAX_B)
+        l0 = log0[b0:b1] if log0 is not None else None
+        _check(lib.nf_conv_rqs(_ptr(h[b0:b1]), _ptr(wfrag), _ptr(bias), _ptr(x_active[b0:b1]), _ptr(l0),
+                               _ptr(y[b0:b1]), _ptr(logj[b0:b1]), b1 - b0, lat4, k4, cin, weight.shape[0],
+                               int(parity), C.byref(opts), int(inverse), _ptr(ws), ws.numel(), NF_F32,
+                               _stream()), "nf_conv_rqs")
+    return y, logj

@@ -24,7 +24,7 @@
 //     uses, so the kernel drops in for the torch convolution -- or, in pair-compact mode,
 //     only the ACTIVE site of every aligned site pair, to (B, Cout, V/2).
 #include <cstdlib>
-#include "nf_internal.h"
+#include "nf_rqs_core.h"
 
 namespace nf {
 
@@ -43,6 +43,11 @@ struct ConvArgs {
   int S;                // LDS plane stride (dwords)
   int cin, cin_pad, cout, kq, nt_total, nt0;
   int act, compact, parity;
+  // fused coupling epilogue (nf_conv_rqs): the logits never leave the CU
+  const float *xact;    // (B, V) field, active sites are transformed
+  float *yout;          // (B, V) out: value at active sites, 0 at frozen sites
+  double *partial;      // (B, gridDim.x) per-workgroup log-det partials
+  RqsParams P;
   int packed, ns;       // packed: K = (tap, ci) flattened, 4 per step, ns steps (multiple of 4)
   int dbg;              // profiling ablation (NF_CONV_DBG): bit0 skip staging, bit1 skip the MFMA loop
 };
@@ -201,9 +206,10 @@ __device__ __forceinline__ void mma_packed(const ConvArgs &A, const float *tile,
   }
 }
 
-template <int MT, int NT, bool COMPACT>
+template <int MT, int NT, bool COMPACT, int FUSE>
 __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
   extern __shared__ __align__(16) float tile[];
+  __shared__ double red[kBlock / kWave];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int nwaves = kBlock / kWave;
@@ -323,6 +329,61 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
     }
   }
 
+  // ---- fused coupling epilogue (FUSE = 1 forward, 2 inverse): accumulators (+bias) -> LDS as
+  // [channel][unit] -> one lane per ACTIVE site runs the RQ-spline map on its 3M-2 logits ->
+  // y pair store + per-workgroup log-det partial.  The (B, C, V/2) logit tensor is never
+  // written to or read from HBM.
+  if constexpr (FUSE > 0) {
+    constexpr int M = NT == 1 ? 4 : (NT == 2 ? 8 : 16);
+    constexpr int C = 3 * M - 2;
+    constexpr int UNITS = (kBlock / kWave) * MT * 16;
+    constexpr int PU = UNITS + 4;                       // row pitch: 16-B aligned rows
+    __syncthreads();                                    // the input tile is dead from here on
+    float *pt = tile;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co = (nt << 4) + (lane & 15);
+        const float bv = (A.bias && co < A.cout) ? A.bias[co] : 0.f;
+        f32x4 v = acc[mt][nt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bv;
+        *reinterpret_cast<f32x4 *>(pt + co * PU + ((wave * MT + mt) << 4) + (g << 2)) = v;
+      }
+    __syncthreads();
+    double lacc = 0.0;
+    if (threadIdx.x < UNITS) {
+      int u = threadIdx.x;
+      const int p3 = u & ((1 << lb3) - 1);
+      u >>= lb3;
+      const int z2 = u & (A.box[2] - 1);
+      u >>= A.lbox[2];
+      const int z1 = u & (A.box[1] - 1);
+      u >>= A.lbox[1];
+      const int z0 = u;
+      const int x0 = o[0] + z0, x1 = o[1] + z1, x2 = o[2] + z2, x3p = o[3] / 2 + p3;
+      if (x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2] && x3p < A.L[3] / 2) {
+        const int off = (A.parity + x0 + x1 + x2) & 1;  // which site of the pair is active
+        const int64_t pair = int64_t(b) * (A.V / 2) + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * (A.L[3] / 2) + x3p;
+        const float2 xv = reinterpret_cast<const float2 *>(A.xact)[pair];
+        RegCol<float, C> a;
+#pragma unroll
+        for (int c = 0; c < C; ++c) a[c] = pt[c * PU + threadIdx.x];
+        float val, logd;
+        rqs_site<float, M, FUSE == 2>(a, A.P, off ? xv.y : xv.x, val, logd);
+        float2 ov;
+        ov.x = off ? 0.f : val;
+        ov.y = off ? val : 0.f;
+        reinterpret_cast<float2 *>(A.yout)[pair] = ov;
+        lacc = double(logd);
+      }
+    }
+    const double tot = block_sum(lacc, red);
+    if (threadIdx.x == 0) A.partial[int64_t(b) * gridDim.x + blockIdx.x] = tot;
+    return;
+  }
+
   // ---- epilogue: C/D layout  col = lane&15 (channel), row = 4*(lane>>4) + reg (site)
   const int64_t Vout = COMPACT ? A.V / 2 : A.V;
   float *__restrict__ out_b = A.out + int64_t(b) * A.cout * Vout;
@@ -369,19 +430,20 @@ static int ilog2(int v) {
   return l;
 }
 
+template <int MT, int NT, bool COMPACT, int FUSE>
+static void launch_one(const ConvArgs &A, dim3 grid, size_t lds, hipStream_t stream) {
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<MT, NT, COMPACT, FUSE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+  hipLaunchKernelGGL((conv_kernel<MT, NT, COMPACT, FUSE>), grid, dim3(kBlock), lds, stream, A);
+}
+
 template <int MT, int NT>
-static void launch(const ConvArgs &A, dim3 grid, size_t lds, hipStream_t stream) {
-  if (A.compact) {
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<MT, NT, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-    hipLaunchKernelGGL((conv_kernel<MT, NT, true>), grid, dim3(kBlock), lds, stream, A);
-  } else {
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<MT, NT, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-    hipLaunchKernelGGL((conv_kernel<MT, NT, false>), grid, dim3(kBlock), lds, stream, A);
-  }
+static void launch(const ConvArgs &A, dim3 grid, size_t lds, int fuse, hipStream_t stream) {
+  if (fuse == 1) launch_one<MT, NT, true, 1>(A, grid, lds, stream);
+  else if (fuse == 2) launch_one<MT, NT, true, 2>(A, grid, lds, stream);
+  else if (A.compact) launch_one<MT, NT, true, 0>(A, grid, lds, stream);
+  else launch_one<MT, NT, false, 0>(A, grid, lds, stream);
 }
 
 }  // namespace nf
@@ -396,12 +458,21 @@ extern "C" int nf_conv_packed_steps(int cin, int ntaps) {
 }
 extern "C" int nf_conv_ntiles(int cout) { return (cout + 15) >> 4; }
 
-extern "C" int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, void *out, int64_t B,
-                           const int32_t *lattice, const int32_t *ksize, int cin, int cout, int act,
-                           int compact, int active_parity, int dtype, void *stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
+struct FuseInfo {           // non-null => the coupling epilogue replaces the store
+  int mode;                 // 1 forward, 2 inverse
+  const float *xact;
+  float *yout;
+  double *partial;
+  size_t partial_bytes;
+  RqsParams P;
+  int64_t *blocks_out;
+};
+
+static int run_conv(const void *in, const void *wfrag, const void *bias, void *out, int64_t B,
+                    const int32_t *lattice, const int32_t *ksize, int cin, int cout, int act, int compact,
+                    int active_parity, int dtype, hipStream_t stream, const FuseInfo *fz) {
   NF_REQUIRE(dtype == NF_F32, "nf_conv_fwd: only NF_F32 is implemented (got dtype %d)", dtype);
-  NF_REQUIRE(in && wfrag && out && lattice && ksize, "nf_conv_fwd: NULL pointer");
+  NF_REQUIRE(in && wfrag && (out || fz) && lattice && ksize, "nf_conv_fwd: NULL pointer");
   NF_REQUIRE(B >= 0 && B <= 65535, "nf_conv_fwd: batch %lld outside [0, 65535]", (long long)B);
   NF_REQUIRE(cin >= 1 && cout >= 1, "nf_conv_fwd: bad channel counts");
   NF_REQUIRE(act >= kActNone && act <= kActSigmoid, "nf_conv_fwd: unknown activation code %d", act);
@@ -494,26 +565,82 @@ extern "C" int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, 
   int64_t rows = 1;
   for (int mu = 0; mu < 3; ++mu) rows *= A.hal[mu];
   NF_REQUIRE(V < (int64_t(1) << 31), "nf_conv_fwd: lattice volume must be < 2^31");
-  const size_t lds = size_t(A.cin_pad) * S * sizeof(float) + size_t(rows) * 2 * sizeof(int) +
+  size_t lds = size_t(A.cin_pad) * S * sizeof(float) + size_t(rows) * 2 * sizeof(int) +
                      (A.packed ? size_t(4) * A.ns * sizeof(int) + 16 : 0);
+  if (fz) {
+    const size_t stage = size_t(48) * ((kBlock / kWave) * MT * 16 + 4) * sizeof(float);
+    if (lds < stage) lds = stage;
+  }
   NF_REQUIRE(lds <= 160 * 1024, "nf_conv_fwd: input box needs %zu B of LDS (> 160 KiB): cin=%d, kernel %dx%dx%dx%d",
              lds, cin, A.k[0], A.k[1], A.k[2], A.k[3]);
   NF_REQUIRE(nblocks <= 0x7fffffff, "nf_conv_fwd: lattice too large");
   const dim3 grid = dim3(static_cast<unsigned>(nblocks), static_cast<unsigned>(B), 1u);
+  int fuse = 0;
+  if (fz) {
+    fuse = fz->mode;
+    A.xact = fz->xact; A.yout = fz->yout; A.partial = fz->partial; A.P = fz->P;
+    NF_REQUIRE(A.nt_total <= 3, "nf_conv_rqs: at most 48 logit channels can be fused");
+    const size_t need = size_t(B) * size_t(nblocks) * sizeof(double);
+    if (fz->partial == nullptr || fz->partial_bytes < need) {
+      set_error("nf_conv_rqs: workspace %zu B < %zu B needed", fz->partial_bytes, need);
+      return NF_EWORKSPACE;
+    }
+    *fz->blocks_out = nblocks;
+  }
   for (int nt0 = 0; nt0 < A.nt_total; nt0 += 3) {
     A.nt0 = nt0;
     const int n = A.nt_total - nt0 >= 3 ? 3 : A.nt_total - nt0;
     if (MT == 4) {
-      if (n == 3) launch<4, 3>(A, grid, lds, stream);
-      else if (n == 2) launch<4, 2>(A, grid, lds, stream);
-      else launch<4, 1>(A, grid, lds, stream);
+      if (n == 3) launch<4, 3>(A, grid, lds, fuse, stream);
+      else if (n == 2) launch<4, 2>(A, grid, lds, fuse, stream);
+      else launch<4, 1>(A, grid, lds, fuse, stream);
     } else {
-      if (n == 3) launch<2, 3>(A, grid, lds, stream);
-      else if (n == 2) launch<2, 2>(A, grid, lds, stream);
-      else launch<2, 1>(A, grid, lds, stream);
+      if (n == 3) launch<2, 3>(A, grid, lds, fuse, stream);
+      else if (n == 2) launch<2, 2>(A, grid, lds, fuse, stream);
+      else launch<2, 1>(A, grid, lds, fuse, stream);
     }
     const int rc = check_launch("conv kernel");
     if (rc) return rc;
   }
   return NF_OK;
+}
+
+extern "C" int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, void *out, int64_t B,
+                           const int32_t *lattice, const int32_t *ksize, int cin, int cout, int act,
+                           int compact, int active_parity, int dtype, void *stream) {
+  return run_conv(in, wfrag, bias, out, B, lattice, ksize, cin, cout, act, compact, active_parity, dtype,
+                  static_cast<hipStream_t>(stream), nullptr);
+}
+
+extern "C" int nf_conv_rqs_supported(int cout, int m) {
+  return (m == 4 || m == 8 || m == 16) && cout == 3 * m - 2;
+}
+
+extern "C" int nf_conv_rqs(const void *in, const void *wfrag, const void *bias, const void *x_active,
+                           const void *log0, void *y, void *logj, int64_t B, const int32_t *lattice,
+                           const int32_t *ksize, int cin, int cout, int active_parity,
+                           const nf_rqs_opts *opts, int inverse, void *workspace, size_t workspace_bytes,
+                           int dtype, void *stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  NF_REQUIRE(opts && x_active && y && logj && lattice, "nf_conv_rqs: NULL pointer");
+  NF_REQUIRE(nf_conv_rqs_supported(cout, opts->m), "nf_conv_rqs: needs knots_len in {4, 8, 16} and cout = 3m-2 (got m=%d, cout=%d)", opts->m, cout);
+  NF_REQUIRE(!opts->fixed_knots_x && !opts->fixed_knots_y, "nf_conv_rqs: fixed knots are not fused");
+  NF_REQUIRE(lattice[3] % 2 == 0, "nf_conv_rqs: needs an even fastest axis");
+  NF_REQUIRE(opts->xhi > opts->xlo && opts->yhi > opts->ylo, "nf_conv_rqs: empty xlim/ylim");
+  if (B == 0) return NF_OK;
+  int64_t blocks = 0;
+  FuseInfo fz{};
+  fz.mode = inverse ? 2 : 1;
+  fz.xact = static_cast<const float *>(x_active);
+  fz.yout = static_cast<float *>(y);
+  fz.partial = static_cast<double *>(workspace);
+  fz.partial_bytes = workspace_bytes;
+  fz.P.xlo = opts->xlo; fz.P.xhi = opts->xhi; fz.P.ylo = opts->ylo; fz.P.yhi = opts->yhi;
+  fz.P.fx = nullptr; fz.P.fy = nullptr;
+  fz.P.m = opts->m; fz.P.el = opts->extrap_left; fz.P.er = opts->extrap_right;
+  fz.blocks_out = &blocks;
+  const int rc = run_conv(in, wfrag, bias, nullptr, B, lattice, ksize, cin, cout, 0, 1, active_parity, dtype,
+                          stream, &fz);
+  if (rc) return rc;
+  return launch_finalize<float>(fz.partial, blocks, log0, logj, B, stream);
 }

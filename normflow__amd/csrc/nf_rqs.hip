@@ -17,7 +17,7 @@
 //              interior knots strictly below the value)
 //   evaluate   src/lib/spline/spline.py:185-220 ; invert :222-287 (stable root)
 //   log-det    src/nn/scalar/couplings_.py:186-188, src/nn/_core.py:38-42
-#include "nf_internal.h"
+#include "nf_rqs_core.h"
 
 namespace nf {
 
@@ -37,247 +37,9 @@ struct RqsArgs {
   int64_t Vp;               // site extent of params: V (full) or V/2 (pair)
   int64_t units;            // work units per sample: V (full) or V/2 (pair)
   int64_t x_bs, y_bs, p_bs; // batch strides (elements)
-  double xlo, xhi, ylo, yhi;
-  const void *fx, *fy;       // optional fixed knot coordinates (m values of T), LDS-column kernels only
-  int m, el, er, layout, iters, C;
+  RqsParams P;              // limits, boundary rules, knots_len, fixed knots
+  int layout, iters, C;
 };
-
-// ------------------------------------------------------------ parameter columns
-template <typename T, int C> struct RegCol {   // static m: logits live in VGPRs
-  T v[C];
-  __device__ __forceinline__ T &operator[](int i) { return v[i]; }
-};
-template <typename T> struct LdsCol {          // runtime m: one LDS column per lane
-  T *p;                                        // row stride = blockDim.x (a multiple of 64):
-  int stride;                                  // bank = lane % 32 for every row, conflict-free
-  __device__ __forceinline__ T &operator[](int i) const { return p[i * stride]; }
-};
-
-template <typename T> struct Pair2;   // two adjacent sites as one 8/16-byte access
-template <> struct Pair2<float> { typedef float2 type; };
-template <> struct Pair2<double> { typedef double2 type; };
-
-template <typename T> struct Site {   // what the scan selects for one site
-  T x0, y0, bw, bh, c0, c1, xe, ye;
-  int j;
-};
-
-// Channel layout of the logits: [x widths (m-1) | y heights (m-1) | derivatives (m)], where
-// the x (y) block is absent when knots_x (knots_y) is fixed (couplings_.py:236-262).
-struct ChanMap { int ox, oy, od; };
-__device__ __forceinline__ ChanMap chan_map(int m, bool fixx, bool fixy) {
-  const int nb = m - 1;
-  ChanMap c;
-  c.ox = 0;
-  c.oy = fixx ? 0 : nb;
-  c.od = (fixx ? 0 : nb) + (fixy ? 0 : nb);
-  return c;
-}
-
-// Softmax numerators in place, then the predicated bin scan.  On return the x and y logit
-// blocks of `a` hold exp(logit - max); sa/sb their sums.  With fixed knot coordinates (only
-// reachable in the LDS-column kernel, MT == 0) bin widths come from the fixed array.
-template <typename T, int MT, bool ON_Y, typename Col>
-__device__ __forceinline__ Site<T> scan_bins(Col &a, const RqsArgs &A, T v, T xlo, T W, T ylo, T H, T &sa,
-                                             T &sb) {
-  const int m = MT > 0 ? MT : A.m;
-  const int nb = m - 1;
-  const T *fx = MT > 0 ? nullptr : static_cast<const T *>(A.fx);
-  const T *fy = MT > 0 ? nullptr : static_cast<const T *>(A.fy);
-  const ChanMap cm = chan_map(m, fx != nullptr, fy != nullptr);
-  sa = T(1);
-  sb = T(1);
-  if (!fx) {
-    T amax = a[cm.ox];
-#pragma unroll
-    for (int k = 1; k < nb; ++k) amax = Num<T>::max(amax, a[cm.ox + k]);
-    sa = T(0);
-#pragma unroll
-    for (int k = 0; k < nb; ++k) {
-      const T e = Num<T>::exp2((a[cm.ox + k] - amax) * Num<T>::kLog2e);
-      a[cm.ox + k] = e;
-      sa += e;
-    }
-  }
-  if (!fy) {
-    T bmax = a[cm.oy];
-#pragma unroll
-    for (int k = 1; k < nb; ++k) bmax = Num<T>::max(bmax, a[cm.oy + k]);
-    sb = T(0);
-#pragma unroll
-    for (int k = 0; k < nb; ++k) {
-      const T e = Num<T>::exp2((a[cm.oy + k] - bmax) * Num<T>::kLog2e);
-      a[cm.oy + k] = e;
-      sb += e;
-    }
-  }
-  const T wx = W / sa, wy = H / sb;
-  Site<T> s;
-  T cx = xlo, cy = ylo;
-  s.x0 = xlo; s.y0 = ylo;
-  s.bw = fx ? fx[1] - fx[0] : a[cm.ox] * wx;
-  s.bh = fy ? fy[1] - fy[0] : a[cm.oy] * wy;
-  s.c0 = a[cm.od]; s.c1 = a[cm.od + 1]; s.j = 0;
-  cx = fx ? fx[1] : cx + s.bw;
-  cy = fy ? fy[1] : cy + s.bh;
-#pragma unroll
-  for (int k = 1; k < nb; ++k) {
-    const T wk = fx ? fx[k + 1] - fx[k] : a[cm.ox + k] * wx;
-    const T hk = fy ? fy[k + 1] - fy[k] : a[cm.oy + k] * wy;
-    const bool sel = (ON_Y ? cy : cx) < v;   // knot k strictly below the value
-    s.x0 = sel ? cx : s.x0;
-    s.y0 = sel ? cy : s.y0;
-    s.bw = sel ? wk : s.bw;
-    s.bh = sel ? hk : s.bh;
-    s.c0 = sel ? a[cm.od + k] : s.c0;
-    s.c1 = sel ? a[cm.od + k + 1] : s.c1;
-    s.j = sel ? k : s.j;
-    cx = fx ? fx[k + 1] : cx + wk;
-    cy = fy ? fy[k + 1] : cy + hk;
-  }
-  s.xe = cx; s.ye = cy;   // last knot as accumulated (the reference's cumsum end)
-  return s;
-}
-
-// Value and log|derivative| of the map at one site.  INV=false: v is x, returns y
-// and log(dy/dx).  INV=true: v is y, returns x and log(dx/dy) = -log g.
-template <typename T, int MT, bool INV, typename Col>
-__device__ __forceinline__ void rqs_site(Col &a, const RqsArgs &A, T v, T &val, T &logd) {
-  const T xlo = T(A.xlo), W = T(A.xhi) - T(A.xlo), ylo = T(A.ylo), H = T(A.yhi) - T(A.ylo);
-  const T in_lo = INV ? ylo : xlo, in_hi = INV ? ylo + H : xlo + W;
-  const T out_lo = INV ? xlo : ylo, out_hi = INV ? xlo + W : ylo + H;
-  const bool refl_l = (A.el == NF_EXTRAP_ANTI) && (v < in_lo);
-  const bool refl_r = (A.er == NF_EXTRAP_ANTI) && (v > in_hi);
-  v = refl_l ? T(2) * in_lo - v : (refl_r ? T(2) * in_hi - v : v);
-  T sa, sb;
-  const Site<T> s = scan_bins<T, MT, INV>(a, A, v, xlo, W, ylo, H, sa, sb);
-  const bool tail_l = (A.el == NF_EXTRAP_LINEAR) && !(in_lo < v);
-  const bool tail_r = (A.er == NF_EXTRAP_LINEAR) && ((INV ? s.ye : s.xe) < v);
-  const T d0 = softplus2(s.c0), d1 = softplus2(s.c1);
-  const T sl = s.bh / s.bw;            // segment slope
-  const T curv = d0 + d1 - T(2) * sl;
-  T th, g;
-  if (!INV) {
-    th = (v - s.x0) / s.bw;
-    const T t1 = th * (T(1) - th);
-    const T den = sl + curv * t1;
-    val = s.y0 + s.bh * (sl * th * th + d0 * t1) / den;
-    const T P = d1 * th * th + T(2) * sl * t1 + d0 * (T(1) - th) * (T(1) - th);
-    g = sl * sl * P / (den * den);
-    val = tail_l ? ylo + d0 * (v - xlo) : (tail_r ? s.ye + d1 * (v - s.xe) : val);
-    g = tail_l ? d0 : (tail_r ? d1 : g);
-    logd = nf_log(g);
-  } else {
-    const T eta = (v - s.y0) / s.bh;
-    const T a2 = -curv * eta + d0 - sl;
-    const T bb = a2 + sl;              // = -a1
-    const T a0 = sl * eta;
-    const T disc = Num<T>::sqrt(Num<T>::max(bb * bb - T(4) * a0 * a2, T(0)));
-    // the root in [0,1], written so that neither branch cancels
-    th = (bb >= T(0)) ? T(2) * a0 / (bb + disc) : (bb - disc) / (T(2) * a2);
-    const T t1 = th * (T(1) - th);
-    const T den = sl + curv * t1;
-    const T P = d1 * th * th + T(2) * sl * t1 + d0 * (T(1) - th) * (T(1) - th);
-    g = sl * sl * P / (den * den);
-    val = s.x0 + s.bw * th;
-    val = tail_l ? xlo + (v - ylo) / d0 : (tail_r ? s.xe + (v - s.ye) / d1 : val);
-    g = tail_l ? d0 : (tail_r ? d1 : g);
-    logd = -nf_log(g);
-  }
-  val = refl_l ? T(2) * out_lo - val : (refl_r ? T(2) * out_hi - val : val);
-}
-
-// VJP at one site.  `x` is the point on the x axis (forward input, or inverse
-// output).  gout / glog are the cotangents of (value, log-det) of the map selected
-// by INV.  Writes the C parameter cotangents back into `a` and returns grad_in.
-template <typename T, int MT, bool INV, typename Col>
-__device__ __forceinline__ T rqs_site_vjp(Col &a, const RqsArgs &A, T x, T gout, T glog) {
-  const int m = MT > 0 ? MT : A.m;
-  const int nb = m - 1;
-  const T xlo = T(A.xlo), W = T(A.xhi) - T(A.xlo), ylo = T(A.ylo), H = T(A.yhi) - T(A.ylo);
-  const bool refl_l = (A.el == NF_EXTRAP_ANTI) && (x < xlo);
-  const bool refl_r = (A.er == NF_EXTRAP_ANTI) && (x > xlo + W);
-  const T sgn = (refl_l || refl_r) ? T(-1) : T(1);
-  const T v = refl_l ? T(2) * xlo - x : (refl_r ? T(2) * (xlo + W) - x : x);
-  T sa, sb;
-  const Site<T> s = scan_bins<T, MT, false>(a, A, v, xlo, W, ylo, H, sa, sb);
-  const bool tail_l = (A.el == NF_EXTRAP_LINEAR) && !(xlo < v);
-  const bool tail_r = (A.er == NF_EXTRAP_LINEAR) && (s.xe < v);
-  const bool tail = tail_l || tail_r;
-  T sg0, sg1;
-  const T d0 = softplus2(s.c0, &sg0), d1 = softplus2(s.c1, &sg1);
-  const T ibw = T(1) / s.bw;
-  const T sl = s.bh * ibw;
-  const T curv = d0 + d1 - T(2) * sl;
-  const T th = (v - s.x0) * ibw;
-  const T om = T(1) - th;
-  const T t1 = th * om;
-  const T den = sl + curv * t1, iden = T(1) / den;
-  const T num = sl * th * th + d0 * t1;
-  const T P = d1 * th * th + T(2) * sl * t1 + d0 * om * om;
-  const T iP = T(1) / P;
-  T g = sl * sl * P * iden * iden;
-  g = tail_l ? d0 : (tail_r ? d1 : g);
-  // dL/dtheta, L = log g (0 on the linear tails)
-  const T Pp = T(2) * (d1 * th + sl * (T(1) - T(2) * th) - d0 * om);
-  const T Lth = tail ? T(0) : (Pp * iP - T(2) * curv * (T(1) - T(2) * th) * iden);
-  // cotangents (gy on the value of the forward map in the actual frame, gl on log g)
-  T gy, gl, grad_in;
-  if (!INV) {
-    gy = gout; gl = glog;
-    grad_in = gy * g + gl * sgn * Lth * ibw;
-  } else {
-    // inverse outputs (x, -L):  dx = (dy - f_p dp)/g ,  d(-L) = -(L_x dx + L_p dp)
-    // => cotangent of y: A1 = (gout - glog L_x)/g ; of p: -A1 f_p - glog L_p
-    const T Lx = sgn * Lth * ibw;
-    const T A1 = (gout - glog * Lx) / g;
-    grad_in = A1;
-    gy = -A1; gl = -glog;
-  }
-  const T gyF = sgn * gy;   // cotangent on F's value in the unreflected frame
-  T d0b, d1b, x0b, wb, y0b, hb;
-  if (tail) {
-    d0b = tail_l ? gyF * (v - xlo) + gl / d0 : T(0);
-    d1b = tail_r ? gyF * (v - s.xe) + gl / d1 : T(0);
-    x0b = wb = y0b = hb = T(0);
-  } else {
-    const T thb = gyF * g * s.bw + gl * Lth;
-    const T i2 = iden * iden;
-    const T slb = gyF * s.bh * (th * th * den - num * (T(1) - T(2) * t1)) * i2 +
-                  gl * (T(2) / sl + T(2) * t1 * iP - T(2) * (T(1) - T(2) * t1) * iden);
-    d0b = gyF * s.bh * t1 * (den - num) * i2 + gl * (om * om * iP - T(2) * t1 * iden);
-    d1b = -gyF * s.bh * num * t1 * i2 + gl * (th * th * iP - T(2) * t1 * iden);
-    hb = gyF * num * iden + slb * ibw;
-    y0b = gyF;
-    x0b = -thb * ibw;
-    wb = -(thb * th + slb * sl) * ibw;
-  }
-  // back through softmax / cumsum (the free x / y blocks of a[] hold the softmax numerators)
-  const bool fixx = MT == 0 && A.fx != nullptr, fixy = MT == 0 && A.fy != nullptr;
-  const ChanMap cm = chan_map(m, fixx, fixy);
-  const T gc0 = d0b * sg0, gc1 = d1b * sg1;
-  if (!fixx) {
-    const T Sx = x0b * (s.x0 - xlo) + wb * s.bw;
-    const T isa = T(1) / sa;
-#pragma unroll
-    for (int k = 0; k < nb; ++k) {
-      const T lead_x = (k < s.j) ? x0b : ((k == s.j) ? wb : T(0));
-      a[cm.ox + k] = a[cm.ox + k] * isa * (W * lead_x - Sx);
-    }
-  }
-  if (!fixy) {
-    const T Sy = y0b * (s.y0 - ylo) + hb * s.bh;
-    const T isb = T(1) / sb;
-#pragma unroll
-    for (int k = 0; k < nb; ++k) {
-      const T lead_y = (k < s.j) ? y0b : ((k == s.j) ? hb : T(0));
-      a[cm.oy + k] = a[cm.oy + k] * isb * (H * lead_y - Sy);
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < m; ++k) a[cm.od + k] = (k == s.j) ? gc0 : ((k == s.j + 1) ? gc1 : T(0));
-  return grad_in;
-}
 
 // ------------------------------------------------------------------ kernels
 // Unit -> (site, parameter column).  PAIR: unit h covers sites 2h, 2h+1 and the
@@ -315,11 +77,11 @@ __global__ __launch_bounds__(kBlock) void rqs_kernel(RqsArgs A) {
         RegCol<T, C> a;
 #pragma unroll
         for (int c = 0; c < C; ++c) a[c] = par[int64_t(c) * A.Vp + u];
-        rqs_site<T, MT, MODE == kInv>(a, A, v, val, logd);
+        rqs_site<T, MT, MODE == kInv>(a, A.P, v, val, logd);
       } else {
         LdsCol<T> a{reinterpret_cast<T *>(smem_raw) + threadIdx.x, int(blockDim.x)};
         for (int c = 0; c < C_rt; ++c) a[c] = par[int64_t(c) * A.Vp + u];
-        rqs_site<T, 0, MODE == kInv>(a, A, v, val, logd);
+        rqs_site<T, 0, MODE == kInv>(a, A.P, v, val, logd);
       }
     }
     if (PAIR) {
@@ -374,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void rqs_vjp_kernel(RqsArgs A) {
       if (active) {
 #pragma unroll
         for (int c = 0; c < C; ++c) a[c] = par[int64_t(c) * A.Vp + u];
-        gi = rqs_site_vjp<T, MT, MODE == kInv>(a, A, v, go, glog);
+        gi = rqs_site_vjp<T, MT, MODE == kInv>(a, A.P, v, go, glog);
       } else {
 #pragma unroll
         for (int c = 0; c < C; ++c) a[c] = T(0);
@@ -385,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void rqs_vjp_kernel(RqsArgs A) {
       LdsCol<T> a{reinterpret_cast<T *>(smem_raw) + threadIdx.x, int(blockDim.x)};
       if (active) {
         for (int c = 0; c < C_rt; ++c) a[c] = par[int64_t(c) * A.Vp + u];
-        gi = rqs_site_vjp<T, 0, MODE == kInv>(a, A, v, go, glog);
+        gi = rqs_site_vjp<T, 0, MODE == kInv>(a, A.P, v, go, glog);
         for (int c = 0; c < C_rt; ++c) gpar[int64_t(c) * A.Vp + u] = a[c];
       } else {
         for (int c = 0; c < C_rt; ++c) gpar[int64_t(c) * A.Vp + u] = T(0);
@@ -420,7 +182,7 @@ static int fill_args(RqsArgs &A, int64_t B, int64_t V, const nf_rqs_opts *o, con
     NF_REQUIRE(!st || (st->x_batch % 2 == 0 && st->y_batch % 2 == 0), "nf_rqs: pair layout needs even batch strides");
   }
   const int C = (o->fixed_knots_x ? 0 : o->m - 1) + (o->fixed_knots_y ? 0 : o->m - 1) + o->m;
-  A.fx = o->fixed_knots_x; A.fy = o->fixed_knots_y; A.C = C;
+  A.P.fx = o->fixed_knots_x; A.P.fy = o->fixed_knots_y; A.C = C;
   A.mask = mask;
   A.V = V;
   A.Vp = o->layout == NF_LAYOUT_PAIR ? V / 2 : V;
@@ -428,8 +190,8 @@ static int fill_args(RqsArgs &A, int64_t B, int64_t V, const nf_rqs_opts *o, con
   A.x_bs = (st && st->x_batch) ? st->x_batch : V;
   A.y_bs = (st && st->y_batch) ? st->y_batch : V;
   A.p_bs = (st && st->params_batch) ? st->params_batch : int64_t(C) * A.Vp;
-  A.xlo = o->xlo; A.xhi = o->xhi; A.ylo = o->ylo; A.yhi = o->yhi;
-  A.m = o->m; A.el = o->extrap_left; A.er = o->extrap_right; A.layout = o->layout;
+  A.P.xlo = o->xlo; A.P.xhi = o->xhi; A.P.ylo = o->ylo; A.P.yhi = o->yhi;
+  A.P.m = o->m; A.P.el = o->extrap_left; A.P.er = o->extrap_right; A.layout = o->layout;
   return NF_OK;
 }
 
@@ -448,7 +210,7 @@ static bool has_static_kernel(int m) {
 // C logits per lane, so it shrinks the workgroup until the tile fits 64 KiB and opts in to
 // the CU's full 160 KiB only for very long splines.  Returns 0 if even 64 lanes do not fit.
 template <typename T> static int pick_block(const RqsArgs &A) {
-  if (has_static_kernel(A.m) && !A.fx && !A.fy) return kBlock;
+  if (has_static_kernel(A.P.m) && !A.P.fx && !A.P.fy) return kBlock;
   const size_t col = size_t(A.C) * sizeof(T);
   int block = kBlock;
   while (block > kWave && col * block > 64 * 1024) block >>= 1;
@@ -459,7 +221,7 @@ template <typename T, int MODE, bool VJP>
 static int dispatch(const RqsArgs &A, dim3 grid, int block, hipStream_t stream) {
   const bool pair = A.layout == NF_LAYOUT_PAIR;
 #define NF_CASE(MV)                                                                         \
-  if (A.m == MV && !A.fx && !A.fy) {                                                                          \
+  if (A.P.m == MV && !A.P.fx && !A.P.fy) {                                                                          \
     if (VJP) {                                                                              \
       if (pair) hipLaunchKernelGGL((rqs_vjp_kernel<T, MV, MODE, true>), grid, dim3(kBlock), 0, stream, A);  \
       else hipLaunchKernelGGL((rqs_vjp_kernel<T, MV, MODE, false>), grid, dim3(kBlock), 0, stream, A);      \
@@ -500,7 +262,7 @@ static int run_map(const void *in, const void *params, const uint8_t *mask, cons
   NF_REQUIRE(in && params && out && logj, "nf_rqs: NULL tensor pointer");
   if (B == 0) return NF_OK;
   const int block = pick_block<T>(A);
-  NF_REQUIRE(block > 0, "nf_rqs: knots_len m=%d does not fit the 160 KiB of LDS of one CU", A.m);
+  NF_REQUIRE(block > 0, "nf_rqs: knots_len m=%d does not fit the 160 KiB of LDS of one CU", A.P.m);
   const Tiling t = make_tiling(A.units, B, block);
   NF_REQUIRE(t.blocks_x <= kMaxBlocksX, "nf_rqs: lattice too large for one launch");
   const size_t need = size_t(B) * size_t(t.blocks_x > 0 ? t.blocks_x : 1) * sizeof(double);
@@ -527,7 +289,7 @@ static int run_vjp(const void *x, const void *params, const uint8_t *mask, const
   NF_REQUIRE(x && params && grad_out && grad_logj && grad_in && grad_params, "nf_rqs_vjp: NULL tensor pointer");
   if (B == 0 || A.units == 0) return NF_OK;
   const int block = pick_block<T>(A);
-  NF_REQUIRE(block > 0, "nf_rqs: knots_len m=%d does not fit the 160 KiB of LDS of one CU", A.m);
+  NF_REQUIRE(block > 0, "nf_rqs: knots_len m=%d does not fit the 160 KiB of LDS of one CU", A.P.m);
   const Tiling t = make_tiling(A.units, B, block);
   A.x = x; A.params = params; A.grad_out = grad_out; A.grad_logj = grad_logj;
   A.grad_in = grad_in; A.grad_params = grad_params; A.iters = t.iters;

@@ -115,8 +115,8 @@ class Coupling_(Module_, ABC):
             out = out.movedim(self.channels_axis, 1)
         return out.reshape(out.shape[0], out.shape[1], -1), _hip.LAYOUT_FULL
 
-    def _slabs(self, B, per_sample_bytes):
-        step = max(1, min(B, PARAM_SLAB_BYTES // max(1, per_sample_bytes)))
+    def _slabs(self, B, per_sample_bytes, budget=None):
+        step = max(1, min(B, (budget or PARAM_SLAB_BYTES) // max(1, per_sample_bytes)))
         return [(b0, min(B, b0 + step)) for b0 in range(0, B, step)]
 
     def _run_atom(self, kernel, x_active, x_frozen, parity, net, log0, n_out_hint):
@@ -208,7 +208,48 @@ class RQSplineCoupling_(Coupling_):
                 raise Exception(f"fixed knots have {k.numel()} entries but the net output implies m={m}")
         return _hip.make_rqs_opts(m, self.xlim, self.ylim, self.extrap, layout, kx, ky)
 
+    # Largest hidden-activation tensor (bytes) the fused path materialises at once.
+    HIDDEN_SLAB_BYTES = 8 << 30
+
+    def _fused_atom(self, inverse, x_active, x_frozen, parity, net, log0):
+        """Inference fast path: ConvAct's last layer and the spline in ONE kernel (nf_conv_rqs);
+        the logits never reach HBM.  Returns None when it does not apply."""
+        if (torch.is_grad_enabled() and (x_active.requires_grad or x_frozen.requires_grad
+                                         or any(p.requires_grad for p in net.parameters()))):
+            return None
+        if (self.propagate_density or self.channels_axis != 1 or self.knots_x is not None
+                or self.knots_y is not None or not hasattr(net, 'hidden_and_last')
+                or not getattr(self.mask, 'pairable', False) or x_active.dtype != torch.float32
+                or not hasattr(self.mask, 'checkerboard_parity')):
+            return None
+        a = self.mask.checkerboard_parity(parity)
+        n_out = net.conv_kwargs['out_channels']
+        if a is None or (n_out + 2) % 3 or not _hip.load().nf_conv_rqs_supported(n_out, (n_out + 2) // 3):
+            return None
+        B = x_active.shape[0]
+        v = x_active.reshape(B, -1)
+        l0 = _hip._log0_tensor(log0, v, B)
+        hidden = max(net.conv_kwargs['hidden_sizes'] or [1])
+        vals, logs = [], []
+        for b0, b1 in self._slabs(B, hidden * v.shape[1] * 4, self.HIDDEN_SLAB_BYTES):
+            got = net.hidden_and_last(self.preprocess_fz(x_frozen[b0:b1]))
+            if got is None:
+                return None
+            h, last = got
+            opts = _hip.make_rqs_opts((n_out + 2) // 3, self.xlim, self.ylim, self.extrap, _hip.LAYOUT_PAIR)
+            val, lj = _hip.conv_rqs(h, last.weight, last.bias, v[b0:b1], None if l0 is None else l0[b0:b1], a,
+                                    opts, inverse)
+            vals.append(val)
+            logs.append(lj)
+        val = vals[0] if len(vals) == 1 else torch.cat(vals)
+        lj = logs[0] if len(logs) == 1 else torch.cat(logs)
+        return val.reshape(x_active.shape), lj
+
     def _atom(self, inverse, *, x_active, x_frozen, parity, net, log0=0):
+        fused = self._fused_atom(inverse, x_active, x_frozen, parity, net, log0)
+        if fused is not None:
+            return fused
+
         def kernel(v, params, l0, act, layout):
             return _hip.RQSCouplingFn.apply(v, params, l0, act, self._opts(params.shape[1], layout, v), inverse)
         return self._run_atom(kernel, x_active, x_frozen, parity, net, log0, 46)

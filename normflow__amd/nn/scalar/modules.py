@@ -114,6 +114,19 @@ class ConvAct(torch.nn.Sequential):
                                 parity=compact_parity or 0)
         return x
 
+    def hidden_and_last(self, x):
+        """(hidden activations after all but the last conv, last conv module) when the stack
+        maps onto the MFMA kernel and the last layer has no activation; else None.  Lets a
+        coupling fuse the last layer with its own kernel."""
+        if self.conv_kwargs.get('pre_act') is not None or x.dim() - 2 != self.conv_kwargs['conv_dim']:
+            return None
+        plan = self._plan()
+        if plan is None or plan[-1][1] != 0 or not _hip.conv_supported(x, plan[0][0].weight):
+            return None
+        for conv, act in plan[:-1]:
+            x = _hip.conv_layer(x, conv.weight, conv.bias, act)
+        return x, plan[-1][0]
+
     def forward(self, x):
         out = self._run_fused(x) if self.conv_kwargs.get('pre_act') is None else None
         return out if out is not None else super().forward(x)

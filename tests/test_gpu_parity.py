@@ -532,3 +532,43 @@ def test_fixed_knots_module_level_vs_oracle():
             tol = 1e-9 if dtype == torch.float64 else 2e-5
             assert rel(y, yo) <= tol and rel(lj, lo) <= tol
             assert rel(xb, x) <= 100 * tol and float(lb.abs().max()) <= 100 * tol
+
+
+@pytest.mark.parametrize("m,shape", [(16, (4, 4, 4, 8)), (8, (6, 8)), (4, (4, 6, 4)), (16, (16, 16, 16)), (16, (10,))])
+def test_fused_conv_spline_epilogue_matches_unfused(m, shape):
+    """nf_conv_rqs (logits accumulator -> LDS -> spline, never in HBM) == conv kernel + coupling
+    kernel run separately (same fp32 arithmetic: tight), and == the fp64 oracle within 1e-5;
+    forward and inverse; clipped boxes (lattices smaller than / not dividing the box)."""
+    torch.manual_seed(m + len(shape))
+    d = len(shape)
+    C = 3 * m - 2
+    net = ConvAct(1, C, 3, conv_dim=d, hidden_sizes=[8, 8], acts=['tanh', 'tanh', None]).to(DEV, torch.float32)
+    with torch.no_grad():
+        for p in list(net.parameters())[-2:]:
+            p.mul_(0.3)
+    mask = EvenOddMask(shape=shape)
+    lim = dict(xlim=(-4.0, 4.0), ylim=(-4.0, 4.0), extrap={'left': 'linear', 'right': 'linear'})
+    cpl = RQSplineCoupling_([net, net], mask=mask, **lim).to(DEV)
+    x = 1.5 * torch.randn((5,) + shape, device=DEV, dtype=torch.float32)
+    for parity in (0, 1):
+        xa, xf = mask.purify(x, parity), mask.purify(x, 1 - parity)
+        l0 = torch.randn(5, device=DEV, dtype=torch.float32)
+        with torch.no_grad():
+            yf, lf = cpl._fused_atom(False, xa, xf, parity, net, l0)
+            params, lay = cpl._params(net, xf, parity)
+            opts = _hip.make_rqs_opts(m, lim["xlim"], lim["ylim"], lim["extrap"], lay)
+            act = mask.activity(parity).reshape(-1).to(DEV)
+            yu, lu = _hip.RQSCouplingFn.apply(xa.reshape(5, -1), params, l0, act, opts, False)
+            assert rel(yf.reshape(5, -1), yu) <= 2e-6 and rel(lf, lu) <= 2e-6
+            xb, lb = cpl._fused_atom(True, yf, xf, parity, net, lf)
+            assert rel(xb, xa) <= 5e-4 and rel(lb, l0) <= 5e-4
+        convs = [mod for mod in net if hasattr(mod, 'weight')]
+        layers = [(c.weight.detach().double().cpu(), c.bias.detach().double().cpu()) for c in convs]
+        out = O.conv_act(xf.double().cpu().unsqueeze(1), layers, ['tanh', 'tanh', None])
+        yo, lo = O.rqs_coupling_atom(xa.double().cpu(), out, O.channel_mask(shape, parity), log0=l0.double().cpu(), **lim)
+        assert rel(yf, yo) <= 1e-5 and rel(lf, lo) <= 1e-5
+    # the block-level API takes the fused path under no_grad and the differentiable path otherwise
+    with torch.no_grad():
+        y1, l1 = cpl(x)
+    y2, l2 = cpl(x.clone().requires_grad_(True))
+    assert rel(y1, y2) <= 2e-6 and rel(l1, l2) <= 2e-6
