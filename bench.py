@@ -99,7 +99,7 @@ def time_rqs_kernel(cpl, lattice, m, dev, reps, layout_pair):
     return dict(seconds=sec, slab=slab, algo_bytes=algo_bytes, gbs=algo_bytes / sec / 1e9)
 
 
-def time_fused_last_layer(cpl, lattice, m, dev, reps):
+def time_fused_last_layer(cpl, lattice, m, dev, reps, batch):
     """Average duration of one nf_conv_rqs launch (last conv layer 8 -> 3m-2 at the active sites
     + fused RQ-spline epilogue) on the slab shape the pipeline uses; HIP events on the launch
     stream.  Algorithmic flops: 2 * 3^d * cin * cout per ACTIVE site (last layer)."""
@@ -109,7 +109,7 @@ def time_fused_last_layer(cpl, lattice, m, dev, reps):
         V *= n
     net = cpl.nets[0]
     hidden = max(net.conv_kwargs['hidden_sizes'])
-    slab = max(1, min(64, cpl.HIDDEN_SLAB_BYTES // (hidden * V * 4)))
+    slab = max(1, min(batch, cpl.HIDDEN_SLAB_BYTES // (hidden * V * 4)))   # the pipeline's own slab
     last = [mod for mod in net if any(True for _ in mod.parameters())][-1]
     g = torch.Generator(device=dev).manual_seed(98)
     h = torch.tanh(torch.randn((slab, hidden) + tuple(lattice), device=dev, dtype=torch.float32, generator=g))
@@ -240,7 +240,7 @@ def main():
                    "algorithmic_bytes_per_launch": kt["algo_bytes"],
                    "in_timed_pipeline": not fused}
         if fused:
-            ft = time_fused_last_layer(cpl, lattice, a.knots, dev, a.kernel_reps)
+            ft = time_fused_last_layer(cpl, lattice, a.knots, dev, max(2, a.kernel_reps // 3), a.batch)
             roof = {"kernel": "nf::conv_kernel<2,3,compact,fused-rqs-fwd> (last conv layer 8->46 at the active sites "
                               "+ RQ-spline coupling epilogue; dominant kernel of the timed region)",
                     "bound": "mfma", "achieved": ft["tflops"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -262,7 +262,7 @@ def main():
             "roofline": roof,
             "roofline_hbm_kernel": hbm_obj,
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:     # CPU baseline: rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(cpl, lattice, a.knots, a.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:

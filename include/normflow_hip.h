@@ -206,6 +206,23 @@ int nf_conv_rqs(const void *in, const void *wfrag, const void *bias, const void 
                 const nf_rqs_opts *opts, int inverse, void *workspace, size_t workspace_bytes,
                 int dtype, void *stream);
 
+/* ---- end points of the flow ------------------------------------------------
+ * nf_phi4_action: S[b] = sum_x (w2 phi^2 + w4 phi^4) - w0 sum_mu sum_x phi(x) phi(x - mu), periodic
+ * (ScalarPhi4Action.action, src/action/scalar_action.py:38-46; w0, w2, w4 from get_coef, :24-36):
+ * ONE pass instead of the reference's d+1.  cfgs (B, V), lattice[4] (leading extents 1 for d < 4),
+ * action (B).  nf_phi4_action_vjp: grad_cfgs = grad_action[b] * dS/dphi.
+ * nf_normal_logprob: logp[b] = sum_x [-(x-loc)^2/(2 s^2) - log s - log sqrt(2 pi)], loc/scale (V)
+ * or NULL (0 / 1) (Prior.log_prob with torch.distributions.Normal, src/prior/prior.py:30-36).
+ */
+int nf_phi4_action(const void *cfgs, void *action, int64_t B, const int32_t *lattice, double w0, double w2,
+                   double w4, void *workspace, size_t workspace_bytes, int dtype, void *stream);
+int nf_phi4_action_vjp(const void *cfgs, const void *grad_action, void *grad_cfgs, int64_t B,
+                       const int32_t *lattice, double w0, double w2, double w4, int dtype, void *stream);
+int nf_normal_logprob(const void *x, const void *loc, const void *scale, void *logp, int64_t B, int64_t V,
+                      void *workspace, size_t workspace_bytes, int dtype, void *stream);
+int nf_normal_logprob_vjp(const void *x, const void *loc, const void *scale, const void *grad_logp,
+                          void *grad_x, int64_t B, int64_t V, int dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,10 @@ PROTOTYPES = {
     "nf_conv_cin_pad": (_I, [_I]),
     "nf_conv_ntiles": (_I, [_I]),
     "nf_conv_packed_steps": (_I, [_I, _I]),
+    "nf_phi4_action": (_I, [_P, _P, _I64, C.POINTER(C.c_int32), _D, _D, _D, _P, _SZ, _I, _P]),
+    "nf_phi4_action_vjp": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), _D, _D, _D, _I, _P]),
+    "nf_normal_logprob": (_I, [_P, _P, _P, _P, _I64, _I64, _P, _SZ, _I, _P]),
+    "nf_normal_logprob_vjp": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I, _P]),
     "nf_conv_rqs_supported": (_I, [_I, _I]),
     "nf_conv_rqs": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I,
                          C.POINTER(RqsOpts), _I, _P, _SZ, _I, _P]),
@@ -494,3 +498,72 @@ def conv_rqs(h, weight, bias, x_active, log0, parity, opts, inverse):
                                int(parity), C.byref(opts), int(inverse), _ptr(ws), ws.numel(), NF_F32,
                                _stream()), "nf_conv_rqs")
     return y, logj
+
+
+# ========================================================================= end points
+def endpoint_supported(t):
+    return t.is_cuda and t.dtype in (torch.float32, torch.float64) and 1 <= t.dim() - 1 <= 4
+
+
+class Phi4ActionFn(torch.autograd.Function):
+    """Per-sample phi^4 action of (B, *L) configurations, one pass (nf_phi4_action)."""
+
+    @staticmethod
+    def forward(ctx, cfgs, w0, w2, w4):
+        cfgs = cfgs.contiguous()
+        B, lat = cfgs.shape[0], list(cfgs.shape[1:])
+        lat4 = (C.c_int32 * 4)(*([1] * (4 - len(lat)) + lat))
+        out = torch.empty(B, dtype=cfgs.dtype, device=cfgs.device)
+        ws = _workspace(min(B, MAX_B), cfgs[0].numel(), cfgs.device)
+        for b0 in range(0, B, MAX_B):
+            b1 = min(B, b0 + MAX_B)
+            _check(load().nf_phi4_action(_ptr(cfgs[b0:b1]), _ptr(out[b0:b1]), b1 - b0, lat4, w0, w2, w4, _ptr(ws),
+                                         ws.numel(), _dtype_code(cfgs), _stream()), "nf_phi4_action")
+        ctx.save_for_backward(cfgs)
+        ctx.w = (w0, w2, w4)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (cfgs,) = ctx.saved_tensors
+        B, lat = cfgs.shape[0], list(cfgs.shape[1:])
+        lat4 = (C.c_int32 * 4)(*([1] * (4 - len(lat)) + lat))
+        g = g.contiguous()
+        gc = torch.empty_like(cfgs)
+        for b0 in range(0, B, MAX_B):
+            b1 = min(B, b0 + MAX_B)
+            _check(load().nf_phi4_action_vjp(_ptr(cfgs[b0:b1]), _ptr(g[b0:b1]), _ptr(gc[b0:b1]), b1 - b0, lat4,
+                                             *ctx.w, _dtype_code(cfgs), _stream()), "nf_phi4_action_vjp")
+        return gc, None, None, None
+
+
+class NormalLogProbFn(torch.autograd.Function):
+    """Per-sample log-density of independent normals (nf_normal_logprob); loc/scale (V) or None."""
+
+    @staticmethod
+    def forward(ctx, x, loc, scale):
+        x = x.contiguous()
+        B = x.shape[0]
+        V = x[0].numel() if B else 0
+        out = torch.empty(B, dtype=x.dtype, device=x.device)
+        ws = _workspace(min(B, MAX_B), V, x.device)
+        for b0 in range(0, B, MAX_B):
+            b1 = min(B, b0 + MAX_B)
+            _check(load().nf_normal_logprob(_ptr(x[b0:b1]), _ptr(loc), _ptr(scale), _ptr(out[b0:b1]), b1 - b0, V,
+                                            _ptr(ws), ws.numel(), _dtype_code(x), _stream()), "nf_normal_logprob")
+        ctx.save_for_backward(x, loc, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, loc, scale = ctx.saved_tensors
+        B = x.shape[0]
+        V = x[0].numel() if B else 0
+        g = g.contiguous()
+        gx = torch.empty_like(x)
+        for b0 in range(0, B, MAX_B):
+            b1 = min(B, b0 + MAX_B)
+            _check(load().nf_normal_logprob_vjp(_ptr(x[b0:b1]), _ptr(loc), _ptr(scale), _ptr(g[b0:b1]),
+                                                _ptr(gx[b0:b1]), b1 - b0, V, _dtype_code(x), _stream()),
+                   "nf_normal_logprob_vjp")
+        return gx, None, None

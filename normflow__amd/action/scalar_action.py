@@ -1,6 +1,8 @@
 """Scalar phi^4 lattice action (reference: src/action/scalar_action.py)."""
 import torch
 
+from .. import _hip
+
 
 class ScalarPhi4Action:
     r"""S = sum_x [ kappa/2 (d_mu phi)^2 + m^2/2 phi^2 + lambda phi^4 ], lattice units
@@ -21,9 +23,12 @@ class ScalarPhi4Action:
         return self.action(cfgs)
 
     def action(self, cfgs):
-        """Per-sample action of a batch of configurations (B, *L) -> (B,)."""
+        """Per-sample action of a batch of configurations (B, *L) -> (B,).  Device tensors take the
+        one-pass HIP kernel (nf_phi4_action); host tensors the op chain below (the reference's)."""
         axes = tuple(range(1, cfgs.ndim))
         w0, w2, w4 = self.get_coef(cfgs.ndim - 1)
+        if _hip.endpoint_supported(cfgs) and all(cfgs.shape[1:]):
+            return _hip.Phi4ActionFn.apply(cfgs, float(w0), float(w2), float(w4))
         sq = cfgs * cfgs
         local = (w2 + w4 * sq) * sq
         hop = sum(cfgs * torch.roll(cfgs, 1, mu) for mu in axes) if axes else 0
