@@ -397,7 +397,8 @@ def pack_conv_weight(w):
 
 
 def conv_supported(x, weight):
-    return x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and 1 <= x.dim() - 2 <= 4
+    return (x.is_cuda and x.dtype in (torch.float32, torch.float64) and weight.dtype == x.dtype
+            and 1 <= x.dim() - 2 <= 4)
 
 
 def _conv_launch(x, wfrag, bias, ksize, cout, act, compact, parity):
@@ -414,7 +415,7 @@ def _conv_launch(x, wfrag, bias, ksize, cout, act, compact, parity):
     for b0 in range(0, B, MAX_B):
         b1 = min(B, b0 + MAX_B)
         _check(lib.nf_conv_fwd(_ptr(x[b0:b1]), _ptr(wfrag), _ptr(bias), _ptr(out[b0:b1]), b1 - b0, lat4, k4,
-                               cin, cout, act, int(compact), int(parity), NF_F32, _stream()), "nf_conv_fwd")
+                               cin, cout, act, int(compact), int(parity), _dtype_code(x), _stream()), "nf_conv_fwd")
     return out
 
 

@@ -29,15 +29,35 @@
 namespace nf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// The 16x16x4 matrix-core instruction per element type.  A: lane l holds A[row l&15][k l>>4];
+// B: B[k l>>4][col l&15]; C/D: col = l&15 and, for f32, rows 4(l>>4)+r, for f64 rows (l>>4)+4r
+// (cdna_hip_programming.md section 3: "f64 MFMA does NOT use these maps").
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+  typedef f32x4 vec4;
+  static constexpr bool kStridedRows = false;
+  static __device__ __forceinline__ vec4 mma(float a, float b, vec4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<double> {
+  typedef f64x4 vec4;
+  static constexpr bool kStridedRows = true;
+  static __device__ __forceinline__ vec4 mma(double a, double b, vec4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+};
 
 enum { kActNone = 0, kActTanh = 1, kActRelu = 2, kActLeakyRelu = 3, kActSoftplus = 4, kActAbs = 5,
        kActSigmoid = 6 };
 
 struct ConvArgs {
-  const float *in;      // (B, Cin, V)
-  const float *wfrag;   // [tap][kq][ntile][64] fragment-ordered, zero padded
-  const float *bias;    // (Cout) or null
-  float *out;           // (B, Cout, V) or (B, Cout, V/2)
+  const void *in;       // (B, Cin, V) of T
+  const void *wfrag;    // [tap][kq][ntile][64] fragment-ordered, zero padded, of T
+  const void *bias;     // (Cout) of T, or null
+  void *out;            // (B, Cout, V) or (B, Cout, V/2) of T
   int64_t V;
   int L[4], k[4], box[4], lbox[4], nbox[4], hal[4];
   int S;                // LDS plane stride (dwords)
@@ -60,6 +80,17 @@ __device__ __forceinline__ float activate(float v, int act) {
     case kActSoftplus: return v > 20.f ? v : log1pf(expf(v));
     case kActAbs: return fabsf(v);
     case kActSigmoid: return 1.f / (1.f + expf(-v));
+    default: return v;
+  }
+}
+__device__ __forceinline__ double activate(double v, int act) {
+  switch (act) {
+    case kActTanh: return tanh(v);
+    case kActRelu: return v > 0. ? v : 0.;
+    case kActLeakyRelu: return v > 0. ? v : 0.01 * v;
+    case kActSoftplus: return v > 20. ? v : log1p(exp(v));
+    case kActAbs: return fabs(v);
+    case kActSigmoid: return 1. / (1. + exp(-v));
     default: return v;
   }
 }
@@ -93,9 +124,9 @@ struct TapWalk {
   }
 };
 
-template <int MT, int NT, int KQ>
-__device__ __forceinline__ void mma_taps(const ConvArgs &A, const float *tile, const int (&abase)[MT],
-                                         const float *__restrict__ wf, f32x4 (&acc)[MT][NT]) {
+template <typename T, int MT, int NT, int KQ>
+__device__ __forceinline__ void mma_taps(const ConvArgs &A, const T *tile, const int (&abase)[MT],
+                                         const T *__restrict__ wf, typename Mma<T>::vec4 (&acc)[MT][NT]) {
   const int ntaps = A.k[0] * A.k[1] * A.k[2] * A.k[3];
   const int wstep = A.nt_total << 6;             // floats per (tap, kq)
   const int S4 = 4 * A.S;
@@ -103,7 +134,7 @@ __device__ __forceinline__ void mma_taps(const ConvArgs &A, const float *tile, c
     TapWalk w{0, 0, 0, 0, 0};
     for (int t = 0; t < ntaps; ++t) {
       for (int q = 0; q < A.kq; ++q) {
-        float a[MT], b[NT];
+        T a[MT], b[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) b[nt] = wf[(int64_t(t) * A.kq + q) * wstep + (nt << 6)];
 #pragma unroll
@@ -112,14 +143,14 @@ __device__ __forceinline__ void mma_taps(const ConvArgs &A, const float *tile, c
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = Mma<T>::mma(a[mt], b[nt], acc[mt][nt]);
       }
       w.next(A, ntaps);
     }
   } else {
-    float a0[KQ][MT], b0[KQ][NT], a1[KQ][MT], b1[KQ][NT];
-    auto request = [&](float (&a)[KQ][MT], float (&b)[KQ][NT], const TapWalk &w) {
-      const float *__restrict__ wt = wf + int64_t(w.tap) * (KQ * wstep);
+    T a0[KQ][MT], b0[KQ][NT], a1[KQ][MT], b1[KQ][NT];
+    auto request = [&](T (&a)[KQ][MT], T (&b)[KQ][NT], const TapWalk &w) {
+      const T *__restrict__ wt = wf + int64_t(w.tap) * (KQ * wstep);
 #pragma unroll
       for (int q = 0; q < KQ; ++q)
 #pragma unroll
@@ -129,14 +160,14 @@ __device__ __forceinline__ void mma_taps(const ConvArgs &A, const float *tile, c
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a[q][mt] = tile[abase[mt] + w.off + q * S4];
     };
-    auto multiply = [&](const float (&a)[KQ][MT], const float (&b)[KQ][NT]) {
+    auto multiply = [&](const T (&a)[KQ][MT], const T (&b)[KQ][NT]) {
 #pragma unroll
       for (int q = 0; q < KQ; ++q)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][mt], b[q][nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = Mma<T>::mma(a[q][mt], b[q][nt], acc[mt][nt]);
     };
     TapWalk w{0, 0, 0, 0, 0};
     request(a0, b0, w);
@@ -162,17 +193,17 @@ __device__ __forceinline__ void mma_taps(const ConvArgs &A, const float *tile, c
 // k-slot is wasted on channel padding.  The k-group g of a lane then needs its OWN LDS offset
 // per step; the offsets live in a small LDS table koff[g][step] (built once per workgroup) and
 // are fetched four steps at a time with one ds_read_b128.
-template <int MT, int NT>
-__device__ __forceinline__ void mma_packed(const ConvArgs &A, const float *tile, const int *koff,
-                                           const int (&abase)[MT], const float *__restrict__ wf,
-                                           f32x4 (&acc)[MT][NT]) {
+template <typename T, int MT, int NT>
+__device__ __forceinline__ void mma_packed(const ConvArgs &A, const T *tile, const int *koff,
+                                           const int (&abase)[MT], const T *__restrict__ wf,
+                                           typename Mma<T>::vec4 (&acc)[MT][NT]) {
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   const int wstep = A.nt_total << 6;
   const int ngroups = A.ns >> 2;
-  float a0[4][MT], b0[4][NT], a1[4][MT], b1[4][NT];
-  auto request = [&](float (&a)[4][MT], float (&b)[4][NT], int grp) {
+  T a0[4][MT], b0[4][NT], a1[4][MT], b1[4][NT];
+  auto request = [&](T (&a)[4][MT], T (&b)[4][NT], int grp) {
     const i32x4 off = *reinterpret_cast<const i32x4 *>(koff + (grp << 2));
-    const float *__restrict__ wt = wf + int64_t(grp) * (4 * wstep);
+    const T *__restrict__ wt = wf + int64_t(grp) * (4 * wstep);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -182,14 +213,14 @@ __device__ __forceinline__ void mma_packed(const ConvArgs &A, const float *tile,
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) a[i][mt] = tile[abase[mt] + off[i]];
   };
-  auto multiply = [&](const float (&a)[4][MT], const float (&b)[4][NT]) {
+  auto multiply = [&](const T (&a)[4][MT], const T (&b)[4][NT]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][mt], b[i][nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = Mma<T>::mma(a[i][mt], b[i][nt], acc[mt][nt]);
   };
   request(a0, b0, 0);
   for (int grp = 0; grp < ngroups; grp += 2) {
@@ -206,9 +237,12 @@ __device__ __forceinline__ void mma_packed(const ConvArgs &A, const float *tile,
   }
 }
 
-template <int MT, int NT, bool COMPACT, int FUSE>
+template <typename T, int MT, int NT, bool COMPACT, int FUSE>
 __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
-  extern __shared__ __align__(16) float tile[];
+  static_assert(FUSE == 0 || sizeof(T) == 4, "the fused coupling epilogue is fp32 only");
+  typedef typename Mma<T>::vec4 acc_t;
+  extern __shared__ __align__(16) unsigned char smem_conv[];
+  T *tile = reinterpret_cast<T *>(smem_conv);
   __shared__ double red[kBlock / kWave];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -222,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
     bid /= A.nbox[mu];
   }
   const int b = blockIdx.y;
-  const float *__restrict__ in_b = A.in + int64_t(b) * A.cin * A.V;
+  const T *__restrict__ in_b = static_cast<const T *>(A.in) + int64_t(b) * A.cin * A.V;
   const int r0 = A.k[0] >> 1, r1 = A.k[1] >> 1, r2 = A.k[2] >> 1, r3 = A.k[3] >> 1;
   const int h0 = A.hal[0], h1 = A.hal[1], h2 = A.hal[2], h3 = A.hal[3];
 
@@ -233,7 +267,8 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
   // (2) each wave then copies rows w, w+4, ...: two broadcast LDS reads per row, then per
   //     channel one coalesced global load and one LDS store, four channels in flight.
   const int R = h0 * h1 * h2;
-  int *rowsrc = reinterpret_cast<int *>(tile + A.cin_pad * A.S);
+  const int tile_ints = int(sizeof(T) / 4) * A.cin_pad * A.S;   // ints occupied by the channel planes
+  int *rowsrc = reinterpret_cast<int *>(tile) + tile_ints;
   int *rowdst = rowsrc + R;
   if (!(A.dbg & 1)) {
     for (int t = threadIdx.x; t < R; t += kBlock) {
@@ -244,9 +279,9 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
       rowsrc[t] = ((x0 * A.L[1] + x1) * A.L[2] + x2) * A.L[3];     // < V <= 2^31 (checked by the launcher)
       rowdst[t] = t * h3;
     }
-    for (int i = threadIdx.x; i < (A.cin_pad - A.cin) * A.S; i += kBlock) tile[A.cin * A.S + i] = 0.f;
+    for (int i = threadIdx.x; i < (A.cin_pad - A.cin) * A.S; i += kBlock) tile[A.cin * A.S + i] = T(0);
     if (A.packed) {                                     // koff[g][step], see mma_packed
-      int *koff = reinterpret_cast<int *>(tile) + ((A.cin_pad * A.S + 2 * R + 3) & ~3);   // 16-B aligned
+      int *koff = reinterpret_cast<int *>(tile) + ((tile_ints + 2 * R + 3) & ~3);   // 16-B aligned
       const int ktot = A.k[0] * A.k[1] * A.k[2] * A.k[3] * A.cin;
       for (int t = threadIdx.x; t < 4 * A.ns; t += kBlock) {
         const int gq = t / A.ns, st = t - gq * A.ns;
@@ -273,9 +308,9 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
         const int src = rowsrc[r] + x3, dst = rowdst[r] + z3;
         int c = 0;
         for (; c + 4 <= A.cin; c += 4) {
-          float v[4];
+          T v[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = in_row ? in_b[int64_t(c + i) * A.V + src] : 0.f;
+          for (int i = 0; i < 4; ++i) v[i] = in_row ? in_b[int64_t(c + i) * A.V + src] : T(0);
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             if (in_row) tile[(c + i) * A.S + dst] = v[i];
@@ -306,26 +341,26 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
     abase[mt] = ((z0 * h1 + z1) * h2 + z2) * h3 + z3 + (A.packed ? 0 : g * A.S);
   }
 
-  f32x4 acc[MT][NT];
+  acc_t acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{T(0), T(0), T(0), T(0)};
 
   // ---- main loop over taps, software pipelined by hand: the A (LDS) and B (global, L1/L2)
   // fragments of tap t+1 are requested before the KQ*MT*NT MFMAs of tap t issue; the loop is
   // unrolled twice over two named fragment buffers so that no register rotation (and hence no
   // early s_waitcnt) sits between a request and its use one tap later.
-  const float *__restrict__ wf = A.wfrag + (int64_t(A.nt0) << 6) + lane;
+  const T *__restrict__ wf = static_cast<const T *>(A.wfrag) + (int64_t(A.nt0) << 6) + lane;
   if (A.packed) {
-    if (!(A.dbg & 2)) mma_packed<MT, NT>(A, tile, reinterpret_cast<const int *>(tile) + ((A.cin_pad * A.S + 2 * R + 3) & ~3) + g * A.ns,
+    if (!(A.dbg & 2)) mma_packed<T, MT, NT>(A, tile, reinterpret_cast<const int *>(tile) + ((tile_ints + 2 * R + 3) & ~3) + g * A.ns,
                                           abase, wf, acc);
   } else if (!(A.dbg & 2)) {
     switch (A.kq) {
-      case 1: mma_taps<MT, NT, 1>(A, tile, abase, wf, acc); break;
-      case 2: mma_taps<MT, NT, 2>(A, tile, abase, wf, acc); break;
-      case 4: mma_taps<MT, NT, 4>(A, tile, abase, wf, acc); break;
-      default: mma_taps<MT, NT, 0>(A, tile, abase, wf, acc); break;
+      case 1: mma_taps<T, MT, NT, 1>(A, tile, abase, wf, acc); break;
+      case 2: mma_taps<T, MT, NT, 2>(A, tile, abase, wf, acc); break;
+      case 4: mma_taps<T, MT, NT, 4>(A, tile, abase, wf, acc); break;
+      default: mma_taps<T, MT, NT, 0>(A, tile, abase, wf, acc); break;
     }
   }
 
@@ -339,17 +374,17 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
     constexpr int UNITS = (kBlock / kWave) * MT * 16;
     constexpr int PU = UNITS + 4;                       // row pitch: 16-B aligned rows
     __syncthreads();                                    // the input tile is dead from here on
-    float *pt = tile;
+    float *pt = reinterpret_cast<float *>(tile);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int co = (nt << 4) + (lane & 15);
-        const float bv = (A.bias && co < A.cout) ? A.bias[co] : 0.f;
-        f32x4 v = acc[mt][nt];
+        const float bv = (A.bias && co < A.cout) ? static_cast<const float *>(A.bias)[co] : 0.f;
+        acc_t v = acc[mt][nt];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += bv;
-        *reinterpret_cast<f32x4 *>(pt + co * PU + ((wave * MT + mt) << 4) + (g << 2)) = v;
+        *reinterpret_cast<acc_t *>(reinterpret_cast<T *>(pt) + co * PU + ((wave * MT + mt) << 4) + (g << 2)) = v;
       }
     __syncthreads();
     double lacc = 0.0;
@@ -384,15 +419,12 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
     return;
   }
 
-  // ---- epilogue: C/D layout  col = lane&15 (channel), row = 4*(lane>>4) + reg (site)
+  // ---- epilogue: C/D layout  col = lane&15 (channel); rows (sites) 4*(lane>>4)+r for f32,
+  // (lane>>4)+4r for f64
   const int64_t Vout = COMPACT ? A.V / 2 : A.V;
-  float *__restrict__ out_b = A.out + int64_t(b) * A.cout * Vout;
+  T *__restrict__ out_b = static_cast<T *>(A.out) + int64_t(b) * A.cout * Vout;
   const int L3u = COMPACT ? A.L[3] / 2 : A.L[3];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    // the 4 units of this lane: consecutive along the fastest box axis (box3 units >= 4 is
-    // guaranteed by the launcher), so they share z0..z2 and form one 16-byte store
-    int u = ((wave * MT + mt) << 4) + (g << 2);
+  auto unit_base = [&](int u, int &x3u, bool &ok) -> int64_t {   // unit -> offset in an output plane
     const int p3 = u & ((1 << lb3) - 1);
     u >>= lb3;
     const int z2 = u & (A.box[2] - 1);
@@ -401,24 +433,48 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
     u >>= A.lbox[1];
     const int z0 = u;
     const int x0 = o[0] + z0, x1 = o[1] + z1, x2 = o[2] + z2;
-    const int x3u = (COMPACT ? o[3] / 2 : o[3]) + p3;
-    const bool row_ok = x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2];
-    const int64_t base = ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * L3u + x3u;
+    x3u = (COMPACT ? o[3] / 2 : o[3]) + p3;
+    ok = x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2];
+    return ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * L3u + x3u;
+  };
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int co = ((A.nt0 + nt) << 4) + (lane & 15);
-      if (!row_ok || co >= A.cout) continue;
-      const float bv = A.bias ? A.bias[co] : 0.f;
-      f32x4 v = acc[mt][nt];
+  for (int mt = 0; mt < MT; ++mt) {
+    if constexpr (!Mma<T>::kStridedRows) {
+      // the 4 units of this lane are consecutive along the fastest box axis (box3 units >= 4 is
+      // guaranteed by the launcher): they share z0..z2 and form one 16-byte store
+      int x3u;
+      bool row_ok;
+      const int64_t base = unit_base(((wave * MT + mt) << 4) + (g << 2), x3u, row_ok);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = activate(v[r] + bv, A.act);
-      float *dst = out_b + int64_t(co) * Vout + base;
-      if (x3u + 3 < L3u && ((Vout | base) & 3) == 0) {
-        *reinterpret_cast<f32x4 *>(dst) = v;
-      } else {
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co = ((A.nt0 + nt) << 4) + (lane & 15);
+        if (!row_ok || co >= A.cout) continue;
+        const T bv = A.bias ? static_cast<const T *>(A.bias)[co] : T(0);
+        acc_t v = acc[mt][nt];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (x3u + r < L3u) dst[r] = v[r];
+        for (int r = 0; r < 4; ++r) v[r] = activate(v[r] + bv, A.act);
+        T *dst = out_b + int64_t(co) * Vout + base;
+        if (x3u + 3 < L3u && ((Vout | base) & 3) == 0) {
+          *reinterpret_cast<acc_t *>(dst) = v;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (x3u + r < L3u) dst[r] = v[r];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int x3u;
+        bool row_ok;
+        const int64_t base = unit_base(((wave * MT + mt) << 4) + g + (r << 2), x3u, row_ok);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int co = ((A.nt0 + nt) << 4) + (lane & 15);
+          if (!row_ok || x3u >= L3u || co >= A.cout) continue;
+          const T bv = A.bias ? static_cast<const T *>(A.bias)[co] : T(0);
+          out_b[int64_t(co) * Vout + base] = activate(acc[mt][nt][r] + bv, A.act);
+        }
       }
     }
   }
@@ -430,20 +486,22 @@ static int ilog2(int v) {
   return l;
 }
 
-template <int MT, int NT, bool COMPACT, int FUSE>
+template <typename T, int MT, int NT, bool COMPACT, int FUSE>
 static void launch_one(const ConvArgs &A, dim3 grid, size_t lds, hipStream_t stream) {
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<MT, NT, COMPACT, FUSE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<T, MT, NT, COMPACT, FUSE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-  hipLaunchKernelGGL((conv_kernel<MT, NT, COMPACT, FUSE>), grid, dim3(kBlock), lds, stream, A);
+  hipLaunchKernelGGL((conv_kernel<T, MT, NT, COMPACT, FUSE>), grid, dim3(kBlock), lds, stream, A);
 }
 
-template <int MT, int NT>
+template <typename T, int MT, int NT>
 static void launch(const ConvArgs &A, dim3 grid, size_t lds, int fuse, hipStream_t stream) {
-  if (fuse == 1) launch_one<MT, NT, true, 1>(A, grid, lds, stream);
-  else if (fuse == 2) launch_one<MT, NT, true, 2>(A, grid, lds, stream);
-  else if (A.compact) launch_one<MT, NT, true, 0>(A, grid, lds, stream);
-  else launch_one<MT, NT, false, 0>(A, grid, lds, stream);
+  if constexpr (sizeof(T) == 4) {
+    if (fuse == 1) return launch_one<T, MT, NT, true, 1>(A, grid, lds, stream);
+    if (fuse == 2) return launch_one<T, MT, NT, true, 2>(A, grid, lds, stream);
+  }
+  if (A.compact) launch_one<T, MT, NT, true, 0>(A, grid, lds, stream);
+  else launch_one<T, MT, NT, false, 0>(A, grid, lds, stream);
 }
 
 }  // namespace nf
@@ -468,10 +526,10 @@ struct FuseInfo {           // non-null => the coupling epilogue replaces the st
   int64_t *blocks_out;
 };
 
-static int run_conv(const void *in, const void *wfrag, const void *bias, void *out, int64_t B,
-                    const int32_t *lattice, const int32_t *ksize, int cin, int cout, int act, int compact,
-                    int active_parity, int dtype, hipStream_t stream, const FuseInfo *fz) {
-  NF_REQUIRE(dtype == NF_F32, "nf_conv_fwd: only NF_F32 is implemented (got dtype %d)", dtype);
+template <typename T>
+static int run_conv_t(const void *in, const void *wfrag, const void *bias, void *out, int64_t B,
+                      const int32_t *lattice, const int32_t *ksize, int cin, int cout, int act, int compact,
+                      int active_parity, hipStream_t stream, const FuseInfo *fz) {
   NF_REQUIRE(in && wfrag && (out || fz) && lattice && ksize, "nf_conv_fwd: NULL pointer");
   NF_REQUIRE(B >= 0 && B <= 65535, "nf_conv_fwd: batch %lld outside [0, 65535]", (long long)B);
   NF_REQUIRE(cin >= 1 && cout >= 1, "nf_conv_fwd: bad channel counts");
@@ -486,10 +544,10 @@ static int run_conv(const void *in, const void *wfrag, const void *bias, void *o
   }
   if (compact) NF_REQUIRE(A.L[3] % 2 == 0, "nf_conv_fwd: pair-compact output needs an even fastest axis");
   if (B == 0 || V == 0) return NF_OK;
-  A.in = static_cast<const float *>(in);
-  A.wfrag = static_cast<const float *>(wfrag);
-  A.bias = static_cast<const float *>(bias);
-  A.out = static_cast<float *>(out);
+  A.in = in;
+  A.wfrag = wfrag;
+  A.bias = bias;
+  A.out = out;
   A.V = V;
   A.cin = cin; A.cin_pad = (cin + 3) & ~3; A.cout = cout; A.kq = A.cin_pad / 4;
   A.nt_total = (cout + 15) >> 4;
@@ -544,7 +602,7 @@ static int run_conv(const void *in, const void *wfrag, const void *bias, void *o
     }
     int64_t hv = 1;
     for (int mu = 0; mu < 4; ++mu) hv *= box[mu] + A.k[mu] - 1;
-    if (MT == 2 || hv * ((cin + 3) & ~3) * 4 <= int64_t(lds_cap_kb) * 1024) break;
+    if (MT == 2 || hv * ((cin + 3) & ~3) * int64_t(sizeof(T)) <= int64_t(lds_cap_kb) * 1024) break;
     MT = 2;
   }
   int64_t nblocks = 1;
@@ -565,7 +623,7 @@ static int run_conv(const void *in, const void *wfrag, const void *bias, void *o
   int64_t rows = 1;
   for (int mu = 0; mu < 3; ++mu) rows *= A.hal[mu];
   NF_REQUIRE(V < (int64_t(1) << 31), "nf_conv_fwd: lattice volume must be < 2^31");
-  size_t lds = size_t(A.cin_pad) * S * sizeof(float) + size_t(rows) * 2 * sizeof(int) +
+  size_t lds = size_t(A.cin_pad) * S * sizeof(T) + size_t(rows) * 2 * sizeof(int) +
                      (A.packed ? size_t(4) * A.ns * sizeof(int) + 16 : 0);
   if (fz) {
     const size_t stage = size_t(48) * ((kBlock / kWave) * MT * 16 + 4) * sizeof(float);
@@ -591,18 +649,29 @@ static int run_conv(const void *in, const void *wfrag, const void *bias, void *o
     A.nt0 = nt0;
     const int n = A.nt_total - nt0 >= 3 ? 3 : A.nt_total - nt0;
     if (MT == 4) {
-      if (n == 3) launch<4, 3>(A, grid, lds, fuse, stream);
-      else if (n == 2) launch<4, 2>(A, grid, lds, fuse, stream);
-      else launch<4, 1>(A, grid, lds, fuse, stream);
+      if (n == 3) launch<T, 4, 3>(A, grid, lds, fuse, stream);
+      else if (n == 2) launch<T, 4, 2>(A, grid, lds, fuse, stream);
+      else launch<T, 4, 1>(A, grid, lds, fuse, stream);
     } else {
-      if (n == 3) launch<2, 3>(A, grid, lds, fuse, stream);
-      else if (n == 2) launch<2, 2>(A, grid, lds, fuse, stream);
-      else launch<2, 1>(A, grid, lds, fuse, stream);
+      if (n == 3) launch<T, 2, 3>(A, grid, lds, fuse, stream);
+      else if (n == 2) launch<T, 2, 2>(A, grid, lds, fuse, stream);
+      else launch<T, 2, 1>(A, grid, lds, fuse, stream);
     }
     const int rc = check_launch("conv kernel");
     if (rc) return rc;
   }
   return NF_OK;
+}
+
+static int run_conv(const void *in, const void *wfrag, const void *bias, void *out, int64_t B,
+                    const int32_t *lattice, const int32_t *ksize, int cin, int cout, int act, int compact,
+                    int active_parity, int dtype, hipStream_t stream, const FuseInfo *fz) {
+  if (dtype == NF_F32)
+    return run_conv_t<float>(in, wfrag, bias, out, B, lattice, ksize, cin, cout, act, compact, active_parity, stream, fz);
+  if (dtype == NF_F64 && fz == nullptr)
+    return run_conv_t<double>(in, wfrag, bias, out, B, lattice, ksize, cin, cout, act, compact, active_parity, stream, fz);
+  set_error("nf_conv: unsupported dtype %d (fp32 and fp64; the fused coupling epilogue is fp32 only)", dtype);
+  return NF_EINVAL;
 }
 
 extern "C" int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, void *out, int64_t B,

@@ -446,8 +446,9 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("lattice,cin,cout,k,act", CONV_CASES)
-def test_conv_kernel_vs_oracle(lattice, cin, cout, k, act):
+def test_conv_kernel_vs_oracle(lattice, cin, cout, k, act, dtype):
     """fp32 MFMA kernel vs the fp64 definition (oracle circular_conv_direct); fp32 products and
     accumulation over K = taps*cin terms: error ~ 1e-7 * sum|a b| (guide: 0.75-1.5e-7 at K<=1024)."""
     d = len(lattice)
@@ -457,10 +458,12 @@ def test_conv_kernel_vs_oracle(lattice, cin, cout, k, act):
     w = 0.3 * torch.randn((cout, cin) + (k,) * d, generator=g, dtype=torch.float64, device='cpu')
     b = torch.randn(cout, generator=g, dtype=torch.float64, device='cpu')
     ref = O._ACTS[act](O.circular_conv_direct(x, w, b))
-    xd, wd, bd = (t.to(DEV, torch.float32) for t in (x, w, b))
+    xd, wd, bd = (t.to(DEV, dtype) for t in (x, w, b))
     out = _hip.conv_layer(xd, wd, bd, _hip.ACT_CODES[act])
-    assert out.shape == ref.shape
+    assert out.shape == ref.shape and out.dtype == dtype
     tol = 1e-6 + 2e-7 * 0.3 * cin * k ** d        # ~ eps_f32 * sum|a b| over K = cin * k^d terms
+    if dtype == torch.float64:                    # v_mfma_f64_16x16x4_f64
+        tol = 1e-12
     assert rel(out, ref) <= tol
     out_nb = _hip.conv_layer(xd, wd, None, 0)
     assert rel(out_nb, O.circular_conv_direct(x, w, None)) <= tol
