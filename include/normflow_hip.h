@@ -171,9 +171,10 @@ int nf_distconv_vjp(const void *v, const void *knots, int K, const void *grad_ou
  * axes of extent 1 and kernel extent 1.
  *
  *   in      (B, cin, V) f32, channel planes (the layout of a torch (B, C, *L) tensor)
- *   wfrag   weights in MFMA-fragment order.  cin % 4 == 0:
- *           [tap][cin/4][ceil(cout/16)][4][16], wfrag[t][q][n][g][j] = W[16n + j][4q + g][t];
- *           otherwise K-packed: [step][ceil(cout/16)][4][16] with
+ *   wfrag   weights in MFMA-fragment order.  nf_conv_packed_steps(cin, ntaps) == 0 (cin a multiple
+ *           of 4, or cin >= 8): [tap][ceil(cin/4)][ceil(cout/16)][4][16],
+ *           wfrag[t][q][n][g][j] = W[16n + j][4q + g][t];
+ *           otherwise (cin in {1,2,3,5,6,7}) K-packed: [step][ceil(cout/16)][4][16] with
  *           wfrag[s][n][g][j] = W[16n + j][kk % cin][kk / cin], kk = 4s + g, for
  *           s < nf_conv_packed_steps(cin, ntaps); 0 where out of range; taps in row-major
  *           kernel order
@@ -222,6 +223,23 @@ int nf_normal_logprob(const void *x, const void *loc, const void *scale, void *l
                       void *workspace, size_t workspace_bytes, int dtype, void *stream);
 int nf_normal_logprob_vjp(const void *x, const void *loc, const void *scale, const void *grad_logp,
                           void *grad_x, int64_t B, int64_t V, int dtype, void *stream);
+
+/* ---- VJP of the conv layer (K5) ---------------------------------------------------------------
+ * grad_input is nf_conv_fwd itself applied to the pre-activation cotangent with the weights
+ * flipped along every kernel axis and in/out channels swapped.  The two entry points below are
+ * the rest of what autograd derives for ConvAct in Fitter.step (src/_normflowcore.py:288):
+ *   nf_act_vjp     grad_pre = grad_out * act'(.), the derivative written through the activation's
+ *                  OUTPUT y (tanh: 1-y^2, relu/leaky: sign test, softplus: 1-e^-y, sigmoid: y(1-y));
+ *   nf_conv_wgrad  gw[o][t*cin + i] += sum_{b,n} gz[b,o,n] * in[b,i,(n + t - k//2) mod L] and
+ *                  gw[o][ntaps*cin] += sum_{b,n} gz[b,o,n] (the bias gradient), accumulated with
+ *                  float atomics into a ZEROED (16*ceil(cout/16), nf_conv_wgrad_cols(cin, ntaps))
+ *                  buffer; cout <= 48 per call; gz is the full-lattice (B, cout, V) cotangent.
+ */
+int nf_act_vjp(const void *grad_out, const void *y, void *grad_pre, int64_t n, int act, int dtype,
+               void *stream);
+int nf_conv_wgrad_cols(int cin, int ntaps);
+int nf_conv_wgrad(const void *in, const void *gz, void *gw, int64_t B, const int32_t *lattice,
+                  const int32_t *ksize, int cin, int cout, int dtype, void *stream);
 
 #ifdef __cplusplus
 }

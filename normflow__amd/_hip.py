@@ -57,6 +57,9 @@ PROTOTYPES = {
     "nf_phi4_action_vjp": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), _D, _D, _D, _I, _P]),
     "nf_normal_logprob": (_I, [_P, _P, _P, _P, _I64, _I64, _P, _SZ, _I, _P]),
     "nf_normal_logprob_vjp": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I, _P]),
+    "nf_act_vjp": (_I, [_P, _P, _P, _I64, _I, _I, _P]),
+    "nf_conv_wgrad_cols": (_I, [_I, _I]),
+    "nf_conv_wgrad": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I, _P]),
     "nf_conv_rqs_supported": (_I, [_I, _I]),
     "nf_conv_rqs": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I,
                          C.POINTER(RqsOpts), _I, _P, _SZ, _I, _P]),
@@ -434,10 +437,44 @@ def _compact_to_full(t, lattice, parity):
     return full.reshape(B, Cc, *lattice)
 
 
+def _lat4(lat, ksize):
+    d = len(lat)
+    return (C.c_int32 * 4)(*([1] * (4 - d) + list(lat))), (C.c_int32 * 4)(*([1] * (4 - d) + list(ksize)))
+
+
+def conv_weight_grad(x, gz, ksize):
+    """(grad_weight (cout, cin, *k), grad_bias (cout)) of a circular conv layer from its input x
+    (B, cin, *L) and the full-lattice pre-activation cotangent gz (B, cout, *L): nf_conv_wgrad."""
+    lib = load()
+    B, cin = x.shape[:2]
+    cout = gz.shape[1]
+    ntaps = 1
+    for k in ksize:
+        ntaps *= k
+    lat4, k4 = _lat4(x.shape[2:], ksize)
+    ncols = lib.nf_conv_wgrad_cols(cin, ntaps)
+    gws, gbs = [], []
+    for c0 in range(0, cout, 48):
+        c1 = min(cout, c0 + 48)
+        part = gz if (c0 == 0 and c1 == cout) else gz[:, c0:c1]
+        part = part.contiguous()
+        buf = torch.zeros(((c1 - c0 + 15) // 16) * 16, ncols, dtype=x.dtype, device=x.device)
+        for b0 in range(0, B, MAX_B):
+            b1 = min(B, b0 + MAX_B)
+            _check(lib.nf_conv_wgrad(_ptr(x[b0:b1]), _ptr(part[b0:b1]), _ptr(buf), b1 - b0, lat4, k4, cin,
+                                     c1 - c0, _dtype_code(x), _stream()), "nf_conv_wgrad")
+        gws.append(buf[:c1 - c0, :ntaps * cin])
+        gbs.append(buf[:c1 - c0, ntaps * cin])
+    gw = torch.cat(gws) if len(gws) > 1 else gws[0]
+    gb = torch.cat(gbs) if len(gbs) > 1 else gbs[0]
+    gw = gw.reshape(cout, ntaps, cin).permute(0, 2, 1).reshape((cout, cin) + tuple(ksize))
+    return gw, gb
+
+
 class ConvFn(torch.autograd.Function):
-    """One circular conv layer + activation.  Forward: the MFMA kernel.  Backward: not yet a
-    HIP kernel -- the cotangents are obtained by differentiating this package's torch-op
-    restatement of the same layer (nn/scalar/convNd.circular_conv)."""
+    """One circular conv layer + activation, forward and backward on the MFMA kernels:
+    forward nf_conv_fwd; backward nf_act_vjp, nf_conv_fwd with flipped / transposed weights
+    (grad_input) and the persistent nf_conv_wgrad kernel (grad_weight, grad_bias)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, act, compact, parity):
@@ -445,29 +482,40 @@ class ConvFn(torch.autograd.Function):
         x = x.contiguous()
         out = _conv_launch(x, pack_conv_weight(weight), bias, weight.shape[2:], weight.shape[0], act,
                            compact, parity)
-        ctx.save_for_backward(x, weight, bias)
-        ctx.act, ctx.compact, ctx.parity = act, compact, parity
+        ctx.save_for_backward(x, weight, out if act else None)
+        ctx.act, ctx.compact, ctx.parity, ctx.has_bias = act, compact, parity, bias is not None
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        from .nn.scalar.convNd import circular_conv
-        x, weight, bias = ctx.saved_tensors
+        x, weight, y = ctx.saved_tensors
+        lib = load()
+        gout = gout.contiguous()
+        gz = gout
+        if ctx.act:
+            gz = torch.empty_like(gout)
+            _check(lib.nf_act_vjp(_ptr(gout), _ptr(y), _ptr(gz), gout.numel(), ctx.act, _dtype_code(gout),
+                                  _stream()), "nf_act_vjp")
         if ctx.compact:
-            gout = _compact_to_full(gout, x.shape[2:], ctx.parity)
-        with torch.enable_grad():
-            xs = x.detach().requires_grad_(True)
-            ws = weight.detach().requires_grad_(True)
-            bs = bias.detach().requires_grad_(True) if bias is not None else None
-            y = _TORCH_ACT[ctx.act](circular_conv(xs, ws, bs, force_torch=True))
-            ins = [xs, ws] + ([bs] if bs is not None else [])
-            grads = torch.autograd.grad(y, ins, gout.reshape(y.shape))
-        return grads[0], grads[1], (grads[2] if bs is not None else None), None, None, None
+            gz = _compact_to_full(gz, x.shape[2:], ctx.parity)
+        gz = gz.reshape((x.shape[0], weight.shape[0]) + tuple(x.shape[2:])).contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            kdims = list(range(2, weight.dim()))
+            wt = weight.detach().flip(kdims).transpose(0, 1).contiguous()
+            gx = _conv_launch(gz, pack_conv_weight(wt), None, wt.shape[2:], wt.shape[0], 0, False, 0)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = conv_weight_grad(x, gz, weight.shape[2:])
+            if not ctx.has_bias:
+                gb = None
+        return gx, gw, gb, None, None, None
 
 
 def conv_layer(x, weight, bias, act=0, compact=False, parity=0):
     """Circular 'same' conv + activation on the HIP kernel; differentiable."""
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+        if act == 5:      # |.| hides the sign its derivative needs: keep the activation outside
+            return torch.abs(ConvFn.apply(x, weight, bias, 0, compact, parity))
         return ConvFn.apply(x, weight, bias, act, compact, parity)
     x = x.contiguous()
     return _conv_launch(x, pack_conv_weight(weight.detach()), None if bias is None else bias.detach(),

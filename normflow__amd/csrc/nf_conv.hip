@@ -62,6 +62,7 @@ struct ConvArgs {
   int L[4], k[4], box[4], lbox[4], nbox[4], hal[4];
   int S;                // LDS plane stride (dwords)
   int cin, cin_pad, cout, kq, nt_total, nt0;
+  int cchunk, kq_total;  // channels staged per pass of the K loop (multiple of 4); cin_pad / 4
   int act, compact, parity;
   // fused coupling epilogue (nf_conv_rqs): the logits never leave the CU
   const float *xact;    // (B, V) field, active sites are transformed
@@ -126,17 +127,18 @@ struct TapWalk {
 
 template <typename T, int MT, int NT, int KQ>
 __device__ __forceinline__ void mma_taps(const ConvArgs &A, const T *tile, const int (&abase)[MT],
-                                         const T *__restrict__ wf, typename Mma<T>::vec4 (&acc)[MT][NT]) {
+                                         const T *__restrict__ wf, typename Mma<T>::vec4 (&acc)[MT][NT],
+                                         int kq0, int kq_n) {
   const int ntaps = A.k[0] * A.k[1] * A.k[2] * A.k[3];
   const int wstep = A.nt_total << 6;             // floats per (tap, kq)
   const int S4 = 4 * A.S;
   if constexpr (KQ == 0) {                       // any channel count: plain loop
     TapWalk w{0, 0, 0, 0, 0};
     for (int t = 0; t < ntaps; ++t) {
-      for (int q = 0; q < A.kq; ++q) {
+      for (int q = 0; q < kq_n; ++q) {
         T a[MT], b[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = wf[(int64_t(t) * A.kq + q) * wstep + (nt << 6)];
+        for (int nt = 0; nt < NT; ++nt) b[nt] = wf[(int64_t(t) * A.kq_total + kq0 + q) * wstep + (nt << 6)];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a[mt] = tile[abase[mt] + w.off + q * S4];
 #pragma unroll
@@ -150,7 +152,7 @@ __device__ __forceinline__ void mma_taps(const ConvArgs &A, const T *tile, const
   } else {
     T a0[KQ][MT], b0[KQ][NT], a1[KQ][MT], b1[KQ][NT];
     auto request = [&](T (&a)[KQ][MT], T (&b)[KQ][NT], const TapWalk &w) {
-      const T *__restrict__ wt = wf + int64_t(w.tap) * (KQ * wstep);
+      const T *__restrict__ wt = wf + (int64_t(w.tap) * A.kq_total + kq0) * wstep;
 #pragma unroll
       for (int q = 0; q < KQ; ++q)
 #pragma unroll
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
   // (2) each wave then copies rows w, w+4, ...: two broadcast LDS reads per row, then per
   //     channel one coalesced global load and one LDS store, four channels in flight.
   const int R = h0 * h1 * h2;
-  const int tile_ints = int(sizeof(T) / 4) * A.cin_pad * A.S;   // ints occupied by the channel planes
+  const int tile_ints = int(sizeof(T) / 4) * A.cchunk * A.S;    // ints occupied by the staged channel planes
   int *rowsrc = reinterpret_cast<int *>(tile) + tile_ints;
   int *rowdst = rowsrc + R;
   if (!(A.dbg & 1)) {
@@ -279,7 +281,6 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
       rowsrc[t] = ((x0 * A.L[1] + x1) * A.L[2] + x2) * A.L[3];     // < V <= 2^31 (checked by the launcher)
       rowdst[t] = t * h3;
     }
-    for (int i = threadIdx.x; i < (A.cin_pad - A.cin) * A.S; i += kBlock) tile[A.cin * A.S + i] = T(0);
     if (A.packed) {                                     // koff[g][step], see mma_packed
       int *koff = reinterpret_cast<int *>(tile) + ((tile_ints + 2 * R + 3) & ~3);   // 16-B aligned
       const int ktot = A.k[0] * A.k[1] * A.k[2] * A.k[3] * A.cin;
@@ -299,28 +300,33 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
         koff[t] = off;
       }
     }
-    __syncthreads();
+  }
+  // copies channels [c0, c0 + cc) of the box + halo into planes [0, cc) of the tile
+  auto stage = [&](int c0, int cc) {
+    if (A.dbg & 1) return;
+    const int creal = A.cin - c0 < cc ? (A.cin - c0 > 0 ? A.cin - c0 : 0) : cc;
+    for (int i = threadIdx.x; i < (cc - creal) * A.S; i += kBlock) tile[creal * A.S + i] = T(0);
     for (int z3b = 0; z3b < h3; z3b += kWave) {         // 64-wide chunks of the fastest axis
       const int z3 = z3b + lane;
       const bool in_row = z3 < h3;
       const int x3 = wrap(o[3] + z3 - r3, A.L[3]);
       for (int r = wave; r < R; r += nwaves) {
         const int src = rowsrc[r] + x3, dst = rowdst[r] + z3;
+        const T *__restrict__ pl = in_b + int64_t(c0) * A.V + src;
         int c = 0;
-        for (; c + 4 <= A.cin; c += 4) {
+        for (; c + 4 <= creal; c += 4) {
           T v[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = in_row ? in_b[int64_t(c + i) * A.V + src] : T(0);
+          for (int i = 0; i < 4; ++i) v[i] = in_row ? pl[int64_t(c + i) * A.V] : T(0);
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             if (in_row) tile[(c + i) * A.S + dst] = v[i];
         }
-        for (; c < A.cin; ++c)
-          if (in_row) tile[c * A.S + dst] = in_b[int64_t(c) * A.V + src];
+        for (; c < creal; ++c)
+          if (in_row) tile[c * A.S + dst] = pl[int64_t(c) * A.V];
       }
     }
-  }
-  __syncthreads();
+  };
 
   // ---- per-lane A-fragment bases: unit -> box coordinates (box dims are powers of two)
   const int g = lane >> 4;                       // k-group of the MFMA fragment
@@ -347,20 +353,29 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{T(0), T(0), T(0), T(0)};
 
-  // ---- main loop over taps, software pipelined by hand: the A (LDS) and B (global, L1/L2)
-  // fragments of tap t+1 are requested before the KQ*MT*NT MFMAs of tap t issue; the loop is
-  // unrolled twice over two named fragment buffers so that no register rotation (and hence no
-  // early s_waitcnt) sits between a request and its use one tap later.
+  // ---- K loop: channel chunks (all of cin at once when it fits LDS) x taps.  Taps are software
+  // pipelined by hand: the A (LDS) and B (global, L1/L2) fragments of tap t+1 are requested
+  // before the KQ*MT*NT MFMAs of tap t issue; the loop is unrolled twice over two named fragment
+  // buffers so that no register rotation (and hence no early s_waitcnt) sits between a request
+  // and its use one tap later.
   const T *__restrict__ wf = static_cast<const T *>(A.wfrag) + (int64_t(A.nt0) << 6) + lane;
-  if (A.packed) {
-    if (!(A.dbg & 2)) mma_packed<T, MT, NT>(A, tile, reinterpret_cast<const int *>(tile) + ((tile_ints + 2 * R + 3) & ~3) + g * A.ns,
-                                          abase, wf, acc);
-  } else if (!(A.dbg & 2)) {
-    switch (A.kq) {
-      case 1: mma_taps<T, MT, NT, 1>(A, tile, abase, wf, acc); break;
-      case 2: mma_taps<T, MT, NT, 2>(A, tile, abase, wf, acc); break;
-      case 4: mma_taps<T, MT, NT, 4>(A, tile, abase, wf, acc); break;
-      default: mma_taps<T, MT, NT, 0>(A, tile, abase, wf, acc); break;
+  __syncthreads();                                      // row tables are visible
+  for (int c0 = 0; c0 < A.cin_pad; c0 += A.cchunk) {
+    const int cc = A.cin_pad - c0 < A.cchunk ? A.cin_pad - c0 : A.cchunk;
+    if (c0) __syncthreads();                            // every wave is done reading the previous chunk
+    stage(c0, cc);
+    __syncthreads();
+    if (A.dbg & 2) continue;
+    if (A.packed) {
+      mma_packed<T, MT, NT>(A, tile, reinterpret_cast<const int *>(tile) + ((tile_ints + 2 * R + 3) & ~3) + g * A.ns,
+                            abase, wf, acc);
+    } else {
+      switch (cc >> 2) {
+        case 1: mma_taps<T, MT, NT, 1>(A, tile, abase, wf, acc, c0 >> 2, 1); break;
+        case 2: mma_taps<T, MT, NT, 2>(A, tile, abase, wf, acc, c0 >> 2, 2); break;
+        case 4: mma_taps<T, MT, NT, 4>(A, tile, abase, wf, acc, c0 >> 2, 4); break;
+        default: mma_taps<T, MT, NT, 0>(A, tile, abase, wf, acc, c0 >> 2, cc >> 2); break;
+      }
     }
   }
 
@@ -511,7 +526,7 @@ using namespace nf;
 extern "C" int nf_conv_cin_pad(int cin) { return (cin + 3) & ~3; }
 // number of 4-wide reduction steps of the K-packed weight layout (cin % 4 != 0), 0 otherwise
 extern "C" int nf_conv_packed_steps(int cin, int ntaps) {
-  if (cin % 4 == 0) return 0;
+  if (cin % 4 == 0 || cin >= 8) return 0;
   return ((((cin * ntaps + 3) / 4) + 3) / 4) * 4;
 }
 extern "C" int nf_conv_ntiles(int cout) { return (cout + 15) >> 4; }
@@ -550,14 +565,15 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
   A.out = out;
   A.V = V;
   A.cin = cin; A.cin_pad = (cin + 3) & ~3; A.cout = cout; A.kq = A.cin_pad / 4;
+  A.kq_total = A.kq; A.cchunk = A.cin_pad;
   A.nt_total = (cout + 15) >> 4;
   A.act = act; A.compact = compact ? 1 : 0; A.parity = active_parity & 1;
-  A.packed = (cin % 4) != 0;
+  A.packed = (cin % 4) != 0 && cin < 8;   // larger odd channel counts: zero-pad to a multiple of 4 and chunk
   if (A.packed) {
     const int ktot = cin * ksize[0] * ksize[1] * ksize[2] * ksize[3];
     A.ns = ((((ktot + 3) / 4) + 3) / 4) * 4;   // steps of 4 k, rounded up to groups of 4 steps
     A.cin_pad = cin;                           // no channel padding in this mode
-    A.kq = 0;
+    A.kq = 0; A.kq_total = 0; A.cchunk = cin;
   }
   {
     static const int dbg = getenv("NF_CONV_DBG") ? atoi(getenv("NF_CONV_DBG")) : 0;
@@ -602,7 +618,8 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
     }
     int64_t hv = 1;
     for (int mu = 0; mu < 4; ++mu) hv *= box[mu] + A.k[mu] - 1;
-    if (MT == 2 || hv * ((cin + 3) & ~3) * int64_t(sizeof(T)) <= int64_t(lds_cap_kb) * 1024) break;
+    const int cplan = A.packed ? cin : (A.cin_pad < 8 ? A.cin_pad : 8);   // channels planned per K pass
+    if (MT == 2 || hv * cplan * int64_t(sizeof(T)) <= int64_t(lds_cap_kb) * 1024) break;
     MT = 2;
   }
   int64_t nblocks = 1;
@@ -623,7 +640,13 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
   int64_t rows = 1;
   for (int mu = 0; mu < 3; ++mu) rows *= A.hal[mu];
   NF_REQUIRE(V < (int64_t(1) << 31), "nf_conv_fwd: lattice volume must be < 2^31");
-  size_t lds = size_t(A.cin_pad) * S * sizeof(T) + size_t(rows) * 2 * sizeof(int) +
+  if (!A.packed) {   // channels per K pass: as many as fit ~78 KiB (at least 4), in steps the pipelined loop knows
+    const int fit = int((int64_t(lds_cap_kb) * 1024) / (int64_t(S) * sizeof(T)));
+    int cc = A.cin_pad;
+    if (cc > fit) cc = fit >= 16 ? 16 : (fit >= 8 ? 8 : 4);
+    A.cchunk = cc;
+  }
+  size_t lds = size_t(A.cchunk) * S * sizeof(T) + size_t(rows) * 2 * sizeof(int) +
                      (A.packed ? size_t(4) * A.ns * sizeof(int) + 16 : 0);
   if (fz) {
     const size_t stage = size_t(48) * ((kBlock / kWave) * MT * 16 + 4) * sizeof(float);
@@ -712,4 +735,287 @@ extern "C" int nf_conv_rqs(const void *in, const void *wfrag, const void *bias, 
                           stream, &fz);
   if (rc) return rc;
   return launch_finalize<float>(fz.partial, blocks, log0, logj, B, stream);
+}
+
+// =====================================================================================
+// VJP of the conv layer w.r.t. weights and bias (what autograd derives for ConvAct in
+// Fitter.step, src/_normflowcore.py:288):
+//     gW[o, i, j] = sum_{b, n} gz[b, o, n] * in[b, i, (n + j - k//2) mod L],   gb[o] = sum gz[b, o, n]
+// GEMM view: rows M = output channels, columns N = (tap, input channel) [+ one all-ones column
+// that yields the bias gradient], reduction K = lattice sites x batch -- enormous K, tiny M x N.
+// So the accumulators stay in registers for the whole launch: workgroups are PERSISTENT, each
+// walks over (sample, box) items, stages the input box + halo and the matching gz box in LDS,
+// and multiplies with K = the 256 sites of the box; wave w owns the N tiles w*NTW .. w*NTW+NTW-1
+// of all M tiles.  One round of float atomics per workgroup at the very end.
+namespace nf {
+
+struct WgArgs {
+  const void *in;       // (B, cin, V)
+  const void *gz;       // (B, cout, V)
+  void *gw;             // (cout_pad16, ncols_pad16) accumulators, zeroed by the caller
+  int64_t V, nitems;
+  int L[4], k[4], box[4], lbox[4], nbox[4], hal[4];
+  int S, PS, units;     // in-tile plane stride, gz-tile plane stride, sites per box
+  int cin, cout, ntot, ncols_pad, nt0, nboxes;
+};
+
+template <typename T> __device__ __forceinline__ void atomic_add(T *p, T v) { atomicAdd(p, v); }
+
+template <typename T, int MTW, int NTW>
+__global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(WgArgs A) {
+  typedef typename Mma<T>::vec4 acc_t;
+  extern __shared__ __align__(16) unsigned char smem_conv[];
+  T *tile = reinterpret_cast<T *>(smem_conv);                 // cin planes of the box + halo
+  T *gzt = tile + A.cin * A.S;                                // MTW*16 planes of the box
+  const int h0 = A.hal[0], h1 = A.hal[1], h2 = A.hal[2], h3 = A.hal[3];
+  const int R = h0 * h1 * h2;
+  int *rowsrc = reinterpret_cast<int *>(gzt + MTW * 16 * A.PS);
+  int *rowdst = rowsrc + R;
+  const int lane = threadIdx.x & 63, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int nwaves = kBlock / kWave;
+  const int r0 = A.k[0] >> 1, r1 = A.k[1] >> 1, r2 = A.k[2] >> 1, r3 = A.k[3] >> 1;
+
+  // per-lane constants of this wave's columns: LDS offset of (tap, ci), or the ones column
+  int coff[NTW];
+  bool one[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    const int n = ((A.nt0 + wave * NTW + nt) << 4) + (lane & 15);
+    coff[nt] = 0;
+    one[nt] = n == A.ntot;
+    if (n < A.ntot) {
+      int tap = n / A.cin;
+      const int ci = n - tap * A.cin;
+      const int j3 = tap % A.k[3]; tap /= A.k[3];
+      const int j2 = tap % A.k[2]; tap /= A.k[2];
+      const int j1 = tap % A.k[1];
+      const int j0 = tap / A.k[1];
+      coff[nt] = ((j0 * h1 + j1) * h2 + j2) * h3 + j3 + ci * A.S;
+    }
+  }
+  acc_t acc[MTW][NTW];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = acc_t{T(0), T(0), T(0), T(0)};
+
+  for (int64_t item = blockIdx.x; item < A.nitems; item += gridDim.x) {
+    const int b = int(item / A.nboxes);
+    int bid = int(item - int64_t(b) * A.nboxes);
+    int o[4];
+#pragma unroll
+    for (int mu = 3; mu >= 0; --mu) {
+      o[mu] = (bid % A.nbox[mu]) * A.box[mu];
+      bid /= A.nbox[mu];
+    }
+    const T *__restrict__ in_b = static_cast<const T *>(A.in) + int64_t(b) * A.cin * A.V;
+    const T *__restrict__ gz_b = static_cast<const T *>(A.gz) + int64_t(b) * A.cout * A.V;
+    __syncthreads();                                  // previous item fully consumed
+    for (int t = threadIdx.x; t < R; t += kBlock) {
+      const int z0 = t / (h1 * h2), rem = t - z0 * (h1 * h2);
+      const int z1 = rem / h2, z2 = rem - z1 * h2;
+      const int x0 = wrap(o[0] + z0 - r0, A.L[0]), x1 = wrap(o[1] + z1 - r1, A.L[1]),
+                x2 = wrap(o[2] + z2 - r2, A.L[2]);
+      rowsrc[t] = ((x0 * A.L[1] + x1) * A.L[2] + x2) * A.L[3];
+      rowdst[t] = t * h3;
+    }
+    // gz box: plane co, unit u (box order); 0 outside the lattice / beyond cout
+    for (int idx = threadIdx.x; idx < MTW * 16 * A.units; idx += kBlock) {
+      const int co = idx / A.units;
+      int u = idx - co * A.units;
+      const int uu = u;
+      const int z3 = u & (A.box[3] - 1); u >>= A.lbox[3];
+      const int z2 = u & (A.box[2] - 1); u >>= A.lbox[2];
+      const int z1 = u & (A.box[1] - 1); u >>= A.lbox[1];
+      const int x0 = o[0] + u, x1 = o[1] + z1, x2 = o[2] + z2, x3 = o[3] + z3;
+      T v = T(0);
+      if (co < A.cout && x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2] && x3 < A.L[3])
+        v = gz_b[int64_t(co) * A.V + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + x3];
+      gzt[co * A.PS + uu] = v;
+    }
+    __syncthreads();                                  // row tables visible
+    for (int z3b = 0; z3b < h3; z3b += kWave) {
+      const int z3 = z3b + lane;
+      const bool in_row = z3 < h3;
+      const int x3 = wrap(o[3] + z3 - r3, A.L[3]);
+      for (int r = wave; r < R; r += nwaves) {
+        const int src = rowsrc[r] + x3, dst = rowdst[r] + z3;
+        for (int c = 0; c < A.cin; ++c)
+          if (in_row) tile[c * A.S + dst] = in_b[int64_t(c) * A.V + src];
+      }
+    }
+    __syncthreads();
+    // K loop over the sites of the box, 4 per MFMA
+    for (int s = 0; s < A.units; s += 4) {
+      int u = s + g;
+      const int uu = u;
+      const int z3 = u & (A.box[3] - 1); u >>= A.lbox[3];
+      const int z2 = u & (A.box[2] - 1); u >>= A.lbox[2];
+      const int z1 = u & (A.box[1] - 1); u >>= A.lbox[1];
+      const int ab = ((u * h1 + z1) * h2 + z2) * h3 + z3;
+      T a[MTW], bq[NTW];
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) a[mt] = gzt[((mt << 4) + (lane & 15)) * A.PS + uu];
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) bq[nt] = one[nt] ? T(1) : tile[ab + coff[nt]];
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = Mma<T>::mma(a[mt], bq[nt], acc[mt][nt]);
+    }
+  }
+  // flush: D col = lane & 15 (n), rows (co) 4g + r (f32) / g + 4r (f64)
+  T *gw = static_cast<T *>(A.gw);
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int n = ((A.nt0 + wave * NTW + nt) << 4) + (lane & 15);
+      if (n >= A.ncols_pad) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = (mt << 4) + (Mma<T>::kStridedRows ? g + (r << 2) : (g << 2) + r);
+        atomic_add(gw + int64_t(co) * A.ncols_pad + n, acc[mt][nt][r]);
+      }
+    }
+}
+
+template <typename T, int MTW>
+static int launch_wgrad(const WgArgs &A0, int ntiles, size_t lds, int grid, hipStream_t stream) {
+  WgArgs A = A0;
+  int nt0 = 0;
+  while (nt0 < ntiles) {
+    const int left = ntiles - nt0;
+    A.nt0 = nt0;
+    int per_wave;
+#define NF_WG(NTW)                                                                                        \
+  {                                                                                                       \
+    if (lds > 64 * 1024)                                                                                  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_kernel<T, MTW, NTW>),          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));                    \
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, MTW, NTW>), dim3(grid), dim3(kBlock), lds, stream, A);       \
+    per_wave = NTW;                                                                                       \
+  }
+    if (left <= 8) NF_WG(2) else if (left <= 24) NF_WG(6) else NF_WG(11)
+#undef NF_WG
+    const int rc = check_launch("conv wgrad kernel");
+    if (rc) return rc;
+    nt0 += 4 * per_wave;
+  }
+  return NF_OK;
+}
+
+template <typename T>
+static int run_wgrad(const void *in, const void *gz, void *gw, int64_t B, const int32_t *lattice,
+                     const int32_t *ksize, int cin, int cout, hipStream_t stream) {
+  NF_REQUIRE(in && gz && gw && lattice && ksize, "nf_conv_wgrad: NULL pointer");
+  NF_REQUIRE(B >= 0 && cin >= 1 && cout >= 1 && cout <= 48, "nf_conv_wgrad: bad sizes (cout <= 48 per call)");
+  WgArgs A{};
+  int64_t V = 1;
+  int ntaps = 1;
+  for (int mu = 0; mu < 4; ++mu) {
+    NF_REQUIRE(lattice[mu] >= 1 && ksize[mu] >= 1 && (ksize[mu] & 1), "nf_conv_wgrad: lattice dims >= 1 and odd kernel sizes needed");
+    A.L[mu] = lattice[mu];
+    A.k[mu] = ksize[mu];
+    V *= lattice[mu];
+    ntaps *= ksize[mu];
+  }
+  NF_REQUIRE(V < (int64_t(1) << 31), "nf_conv_wgrad: lattice volume must be < 2^31");
+  if (B == 0 || V == 0) return NF_OK;
+  const int MTW = (cout + 15) >> 4;
+  // box of 256 (fp32) / 128 (fp64) sites, same shape rule as the forward kernel
+  const int target = sizeof(T) == 4 ? 256 : 128;
+  int box[4], cap[4];
+  for (int mu = 0; mu < 4; ++mu) { cap[mu] = 1 << ilog2(A.L[mu]); box[mu] = 1; }
+  box[3] = cap[3] < 32 ? cap[3] : 32;
+  if (box[3] < 4) box[3] = 4;
+  int vol = box[3];
+  while (vol < target) {
+    int best = -1;
+    for (int mu = 2; mu >= 0; --mu)
+      if (box[mu] < cap[mu] && (best < 0 || box[mu] < box[best])) best = mu;
+    if (best < 0) { if (box[3] < cap[3]) best = 3; else break; }
+    box[best] *= 2;
+    vol *= 2;
+  }
+  while (vol < target) { box[3] *= 2; vol *= 2; }
+  int64_t halvol = 1, nboxes = 1, rows = 1;
+  for (int mu = 0; mu < 4; ++mu) {
+    A.box[mu] = box[mu];
+    A.lbox[mu] = ilog2(box[mu]);
+    A.nbox[mu] = (A.L[mu] + box[mu] - 1) / box[mu];
+    A.hal[mu] = box[mu] + A.k[mu] - 1;
+    halvol *= A.hal[mu];
+    nboxes *= A.nbox[mu];
+    if (mu < 3) rows *= A.hal[mu];
+  }
+  A.units = vol;
+  A.S = int(halvol) | 1;
+  A.PS = vol + 2;                                    // gz planes: banks 2*co + k-group, conflict-free
+  A.cin = cin; A.cout = cout; A.ntot = ntaps * cin;
+  const int ntiles = (A.ntot + 1 + 15) >> 4;
+  A.ncols_pad = ntiles << 4;
+  A.nboxes = int(nboxes);
+  A.nitems = int64_t(B) * nboxes;
+  A.V = V; A.in = in; A.gz = gz; A.gw = gw;
+  const size_t lds = (size_t(cin) * A.S + size_t(MTW) * 16 * A.PS) * sizeof(T) + size_t(rows) * 2 * sizeof(int);
+  NF_REQUIRE(lds <= 160 * 1024, "nf_conv_wgrad: needs %zu B of LDS (> 160 KiB): cin=%d", lds, cin);
+  const int grid = int(A.nitems < 512 ? A.nitems : 512);
+  if (MTW == 1) return launch_wgrad<T, 1>(A, ntiles, lds, grid, stream);
+  if (MTW == 2) return launch_wgrad<T, 2>(A, ntiles, lds, grid, stream);
+  return launch_wgrad<T, 3>(A, ntiles, lds, grid, stream);
+}
+
+// d(activation)/d(pre-activation) expressed through the activation's OUTPUT y
+template <typename T> __global__ __launch_bounds__(kBlock) void act_vjp_kernel(const T *__restrict__ gout,
+                                                                                 const T *__restrict__ y,
+                                                                                 T *__restrict__ gz, int64_t n, int act) {
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kBlock) {
+    const T v = y[i];
+    T d = T(1);
+    switch (act) {
+      case kActTanh: d = T(1) - v * v; break;
+      case kActRelu: d = v > T(0) ? T(1) : T(0); break;
+      case kActLeakyRelu: d = v > T(0) ? T(1) : T(0.01); break;
+      case kActSoftplus: d = T(1) - (sizeof(T) == 4 ? T(expf(-float(v))) : T(exp(-double(v)))); break;
+      case kActSigmoid: d = v * (T(1) - v); break;
+      default: break;
+    }
+    gz[i] = gout[i] * d;
+  }
+}
+
+}  // namespace nf
+
+extern "C" int nf_conv_wgrad_cols(int cin, int ntaps) { return (((cin * ntaps + 1) + 15) >> 4) << 4; }
+
+extern "C" int nf_conv_wgrad(const void *in, const void *gz, void *gw, int64_t B, const int32_t *lattice,
+                             const int32_t *ksize, int cin, int cout, int dtype, void *stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == NF_F32) return run_wgrad<float>(in, gz, gw, B, lattice, ksize, cin, cout, s);
+  if (dtype == NF_F64) return run_wgrad<double>(in, gz, gw, B, lattice, ksize, cin, cout, s);
+  set_error("nf_conv_wgrad: unsupported dtype %d", dtype);
+  return NF_EINVAL;
+}
+
+extern "C" int nf_act_vjp(const void *grad_out, const void *y, void *grad_pre, int64_t n, int act, int dtype,
+                          void *stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  NF_REQUIRE(grad_out && y && grad_pre && n >= 0, "nf_act_vjp: bad arguments");
+  NF_REQUIRE(act >= kActNone && act <= kActSigmoid && act != kActAbs, "nf_act_vjp: activation %d has no output-only derivative", act);
+  if (n == 0) return NF_OK;
+  const int64_t want = (n + kBlock - 1) / kBlock;
+  const unsigned grid = unsigned(want < 8192 ? want : 8192);
+  if (dtype == NF_F32)
+    hipLaunchKernelGGL((act_vjp_kernel<float>), dim3(grid), dim3(kBlock), 0, s, static_cast<const float *>(grad_out),
+                       static_cast<const float *>(y), static_cast<float *>(grad_pre), n, act);
+  else if (dtype == NF_F64)
+    hipLaunchKernelGGL((act_vjp_kernel<double>), dim3(grid), dim3(kBlock), 0, s, static_cast<const double *>(grad_out),
+                       static_cast<const double *>(y), static_cast<double *>(grad_pre), n, act);
+  else {
+    set_error("nf_act_vjp: unsupported dtype %d", dtype);
+    return NF_EINVAL;
+  }
+  return check_launch("act vjp kernel");
 }

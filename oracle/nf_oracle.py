@@ -357,7 +357,7 @@ def circular_conv_fast(x, weight, bias=None):
 _ACTS = {
     None: lambda t: t, 'none': lambda t: t, 'tanh': torch.tanh, 'relu': torch.relu,
     'leaky_relu': lambda t: F.leaky_relu(t), 'softplus': lambda t: F.softplus(t),
-    'abs': torch.abs,
+    'abs': torch.abs, 'expit': torch.sigmoid,
 }
 
 

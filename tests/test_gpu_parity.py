@@ -443,6 +443,8 @@ CONV_CASES = [
     ((4, 6, 4), 8, 8, 3, 'tanh'), ((16, 16, 16), 8, 46, 3, None), ((4, 4, 10), 5, 17, 3, 'softplus'),
     ((4, 4, 2, 6), 1, 8, 3, 'tanh'), ((8, 8, 8, 8), 8, 46, 3, None), ((4, 2, 4, 4), 8, 70, 3, 'abs'),
     ((6, 6, 6, 12), 8, 8, 3, 'tanh'), ((4, 4, 4, 64), 2, 4, 3, None),
+    # many input channels: the K loop runs in channel chunks that fit LDS (and odd counts >= 8 are zero-padded)
+    ((8, 8, 8, 8), 48, 8, 3, None), ((4, 4, 4, 8), 46, 5, 3, 'tanh'), ((16, 16), 22, 3, 3, None), ((6, 8, 8), 10, 12, 3, None),
 ]
 
 
@@ -610,3 +612,37 @@ def test_endpoint_kernels_against_goldens(golden, dtype):
     ref = torch.distributions.Normal(loc, sc).log_prob(x).sum(dim=(1, 2))
     pr = NormalPrior(loc=loc.to(DEV, dtype), scale=sc.to(DEV, dtype))
     assert rel(pr.log_prob(x.to(DEV, dtype)), ref) <= 10 * tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("lattice,cin,cout,act", [((4, 4, 4, 8), 8, 46, None), ((4, 4, 4, 8), 1, 8, 'tanh'),
+                                                  ((6, 8), 8, 8, 'tanh'), ((10,), 3, 5, 'softplus'),
+                                                  ((4, 6, 4), 8, 22, 'leaky_relu'), ((8, 8, 8, 8), 8, 50, 'relu'),
+                                                  ((6, 4), 2, 2, 'abs'), ((3, 5), 4, 3, 'expit')])
+def test_conv_vjp_kernels_vs_autograd(lattice, cin, cout, act, dtype):
+    """ConvFn.backward (nf_act_vjp + nf_conv_fwd with flipped weights + nf_conv_wgrad) against
+    autograd through the fp64 oracle convolution; also the pair-compact output mode."""
+    d = len(lattice)
+    g = torch.Generator(device='cpu').manual_seed(cin * 100 + cout)
+    x = torch.randn((3, cin) + lattice, generator=g, dtype=torch.float64, device='cpu')
+    w = 0.3 * torch.randn((cout, cin) + (3,) * d, generator=g, dtype=torch.float64, device='cpu')
+    b = torch.randn(cout, generator=g, dtype=torch.float64, device='cpu')
+    go = torch.randn((3, cout) + lattice, generator=g, dtype=torch.float64, device='cpu')
+    xo, wo, bo = (t.clone().requires_grad_(True) for t in (x, w, b))
+    ref = O._ACTS[act](O.circular_conv_direct(xo, wo, bo))
+    gref = torch.autograd.grad(ref, (xo, wo, bo), go, retain_graph=True)
+    xd, wd, bd = (t.to(DEV, dtype).requires_grad_(True) for t in (x, w, b))
+    out = _hip.conv_layer(xd, wd, bd, _hip.ACT_CODES[act])
+    got = torch.autograd.grad(out, (xd, wd, bd), go.to(DEV, dtype))
+    tol = 1e-10 if dtype == torch.float64 else 2e-5
+    for a_, r_ in zip(got, gref):
+        assert rel(a_, r_) <= tol * max(1.0, float(r_.abs().max()) ** 0)
+    if lattice[-1] % 2 == 0 and act != 'abs':
+        act_mask = (O.even_odd_mask(lattice, parity=0) == 1).reshape(-1)          # coordinate sum even
+        outc = _hip.conv_layer(xd, wd, bd, _hip.ACT_CODES[act], compact=True, parity=0)
+        goc = compact(go.reshape(3, cout, -1).to(DEV, dtype), act_mask.to(torch.uint8).to(DEV))
+        gotc = torch.autograd.grad(outc, (xd, wd, bd), goc)
+        gom = go * act_mask.reshape((1, 1) + lattice).double()
+        grefc = torch.autograd.grad(ref, (xo, wo, bo), gom)
+        for a_, r_ in zip(gotc, grefc):
+            assert rel(a_, r_) <= tol
