@@ -184,6 +184,10 @@ int nf_distconv_vjp(const void *v, const void *knots, int K, const void *grad_ou
  *           (NF_LAYOUT_PAIR input of the coupling kernels)
  *   act     0 none, 1 tanh, 2 relu, 3 leaky_relu(0.01), 4 softplus, 5 abs, 6 sigmoid
  */
+/* nf_conv_two_site(cout, compact, L3, k3) != 0: the layer is computed with two-site column packing
+ * (cout <= 8): pass wfrag packed from the (16, cin, k0, k1, k2, k3+1) tensor W2 with
+ * W2[o][..][t3] = W[o][..][t3] (t3 < k3) and W2[8+o][..][t3] = W[o][..][t3-1] (t3 >= 1), else 0. */
+int nf_conv_two_site(int cout, int compact, int l3, int k3);
 int nf_conv_cin_pad(int cin);
 int nf_conv_ntiles(int cout);
 int nf_conv_packed_steps(int cin, int ntaps);

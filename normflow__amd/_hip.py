@@ -50,6 +50,7 @@ PROTOTYPES = {
     "nf_affine_vjp": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _I, _I, _P]),
     "nf_distconv": (_I, [_P, _P, _I, _P, _P, _P, _I64, _I64, _I, _I, _P, _SZ, _I, _P]),
     "nf_distconv_vjp": (_I, [_P, _P, _I, _P, _P, _P, _P, _I64, _I64, _I, _I, _P, _SZ, _I, _P]),
+    "nf_conv_two_site": (_I, [_I, _I, _I, _I]),
     "nf_conv_cin_pad": (_I, [_I]),
     "nf_conv_ntiles": (_I, [_I]),
     "nf_conv_packed_steps": (_I, [_I, _I]),
@@ -404,13 +405,25 @@ def conv_supported(x, weight):
             and 1 <= x.dim() - 2 <= 4)
 
 
-def _conv_launch(x, wfrag, bias, ksize, cout, act, compact, parity):
+def _conv_launch(x, weight, bias, act, compact, parity):
+    """One launch sequence of nf_conv_fwd for a (cout, cin, *k) weight tensor; packs the weights in
+    the fragment layout the library will use (two-site column packing for cout <= 8)."""
     lib = load()
     B, cin = x.shape[:2]
     lat = list(x.shape[2:])
+    cout, ksize = weight.shape[0], list(weight.shape[2:])
     d = len(lat)
     lat4 = (C.c_int32 * 4)(*([1] * (4 - d) + lat))
-    k4 = (C.c_int32 * 4)(*([1] * (4 - d) + list(ksize)))
+    k4 = (C.c_int32 * 4)(*([1] * (4 - d) + ksize))
+    if lib.nf_conv_two_site(cout, int(compact), lat[-1], ksize[-1]):
+        # 16 columns: [0, cout) = the layer at site 2p (taps 0..k3-1), [8, 8+cout) = the same
+        # channels at site 2p+1 (taps 1..k3): one extra tap along the fastest axis
+        w2 = weight.new_zeros((16, cin) + tuple(ksize[:-1]) + (ksize[-1] + 1,))
+        w2[:cout, ..., :ksize[-1]] = weight
+        w2[8:8 + cout, ..., 1:] = weight
+        wfrag = pack_conv_weight(w2)
+    else:
+        wfrag = pack_conv_weight(weight)
     V = 1
     for n in lat:
         V *= n
@@ -480,8 +493,7 @@ class ConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, act, compact, parity):
         _require_device(x, weight, bias)
         x = x.contiguous()
-        out = _conv_launch(x, pack_conv_weight(weight), bias, weight.shape[2:], weight.shape[0], act,
-                           compact, parity)
+        out = _conv_launch(x, weight.detach(), bias, act, compact, parity)
         ctx.save_for_backward(x, weight, out if act else None)
         ctx.act, ctx.compact, ctx.parity, ctx.has_bias = act, compact, parity, bias is not None
         return out
@@ -503,7 +515,7 @@ class ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             kdims = list(range(2, weight.dim()))
             wt = weight.detach().flip(kdims).transpose(0, 1).contiguous()
-            gx = _conv_launch(gz, pack_conv_weight(wt), None, wt.shape[2:], wt.shape[0], 0, False, 0)
+            gx = _conv_launch(gz, wt, None, 0, False, 0)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw, gb = conv_weight_grad(x, gz, weight.shape[2:])
             if not ctx.has_bias:
@@ -518,8 +530,7 @@ def conv_layer(x, weight, bias, act=0, compact=False, parity=0):
             return torch.abs(ConvFn.apply(x, weight, bias, 0, compact, parity))
         return ConvFn.apply(x, weight, bias, act, compact, parity)
     x = x.contiguous()
-    return _conv_launch(x, pack_conv_weight(weight.detach()), None if bias is None else bias.detach(),
-                        weight.shape[2:], weight.shape[0], act, compact, parity)
+    return _conv_launch(x, weight.detach(), None if bias is None else bias.detach(), act, compact, parity)
 
 
 def conv_rqs(h, weight, bias, x_active, log0, parity, opts, inverse):

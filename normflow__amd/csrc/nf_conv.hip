@@ -62,6 +62,8 @@ struct ConvArgs {
   int L[4], k[4], box[4], lbox[4], nbox[4], hal[4];
   int S;                // LDS plane stride (dwords)
   int cin, cin_pad, cout, kq, nt_total, nt0;
+  int kt3;              // taps walked along the fastest axis: k[3], or k[3]+1 in two-site mode
+  int sh2;              // two-site column packing (cout <= 8): cols 0-7 -> site 2p, cols 8-15 -> site 2p+1
   int cchunk, kq_total;  // channels staged per pass of the K loop (multiple of 4); cin_pad / 4
   int act, compact, parity;
   // fused coupling epilogue (nf_conv_rqs): the logits never leave the CU
@@ -110,9 +112,9 @@ struct TapWalk {
     ++tap;
     const int h3 = A.hal[3], h2 = A.hal[2], h1 = A.hal[1];
     ++off;
-    if (++j3 == A.k[3]) {
+    if (++j3 == A.kt3) {
       j3 = 0;
-      off += h3 - A.k[3];
+      off += h3 - A.kt3;
       if (++j2 == A.k[2]) {
         j2 = 0;
         off += (h2 - A.k[2]) * h3;
@@ -129,7 +131,7 @@ template <typename T, int MT, int NT, int KQ>
 __device__ __forceinline__ void mma_taps(const ConvArgs &A, const T *tile, const int (&abase)[MT],
                                          const T *__restrict__ wf, typename Mma<T>::vec4 (&acc)[MT][NT],
                                          int kq0, int kq_n) {
-  const int ntaps = A.k[0] * A.k[1] * A.k[2] * A.k[3];
+  const int ntaps = A.k[0] * A.k[1] * A.k[2] * A.kt3;
   const int wstep = A.nt_total << 6;             // floats per (tap, kq)
   const int S4 = 4 * A.S;
   if constexpr (KQ == 0) {                       // any channel count: plain loop
@@ -186,6 +188,77 @@ __device__ __forceinline__ void mma_taps(const ConvArgs &A, const T *tile, const
         multiply(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
       }
+    }
+  }
+}
+
+// Kernel rows: when the fastest kernel axis has extent 3 (the ConvAct default) one pipelined
+// iteration covers the 3 taps of a row at once -- their LDS offsets differ by 1 element, which the
+// ds_read encodes as an immediate -- so the uniform walk / address arithmetic is paid once per
+// 3*KQ*MT*NT MFMAs instead of once per KQ*MT*NT.
+template <typename T, int MT, int NT, int KQ, int K3>
+__device__ __forceinline__ void mma_rows(const ConvArgs &A, const T *tile, const int (&abase)[MT],
+                                          const T *__restrict__ wf, typename Mma<T>::vec4 (&acc)[MT][NT],
+                                          int kq0) {
+  const int nrows = A.k[0] * A.k[1] * A.k[2];
+  const int wstep = A.nt_total << 6;
+  const int S4 = 4 * A.S;
+  const int h3 = A.hal[3], h2 = A.hal[2], h1 = A.hal[1];
+  T a0[K3][KQ][MT], b0[K3][KQ][NT], a1[K3][KQ][MT], b1[K3][KQ][NT];
+  int j1 = 0, j2 = 0, off = 0, row = 0;                 // uniform walk over (j0, j1, j2)
+  auto next = [&]() {
+    if (row + 1 >= nrows) return;                       // clamp at the last row (harmless re-read)
+    ++row;
+    off += h3;
+    if (++j2 == A.k[2]) {
+      j2 = 0;
+      off += (h2 - A.k[2]) * h3;
+      if (++j1 == A.k[1]) {
+        j1 = 0;
+        off += (h1 - A.k[1]) * h2 * h3;
+      }
+    }
+  };
+  auto request = [&](T (&a)[K3][KQ][MT], T (&b)[K3][KQ][NT]) {
+    const T *__restrict__ wt = wf + (int64_t(row) * K3 * A.kq_total + kq0) * wstep;
+#pragma unroll
+    for (int j3 = 0; j3 < K3; ++j3)
+#pragma unroll
+      for (int q = 0; q < KQ; ++q)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[j3][q][nt] = wt[(int64_t(j3) * A.kq_total + q) * wstep + (nt << 6)];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const T *pa = tile + abase[mt] + off + q * S4;
+#pragma unroll
+        for (int j3 = 0; j3 < K3; ++j3) a[j3][q][mt] = pa[j3];
+      }
+  };
+  auto multiply = [&](const T (&a)[K3][KQ][MT], const T (&b)[K3][KQ][NT]) {
+#pragma unroll
+    for (int j3 = 0; j3 < K3; ++j3)
+#pragma unroll
+      for (int q = 0; q < KQ; ++q)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Mma<T>::mma(a[j3][q][mt], b[j3][q][nt], acc[mt][nt]);
+  };
+  request(a0, b0);
+  for (int r = 0; r < nrows; r += 2) {
+    next();
+    request(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (r + 1 < nrows) {
+      next();
+      request(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
@@ -283,7 +356,7 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
     }
     if (A.packed) {                                     // koff[g][step], see mma_packed
       int *koff = reinterpret_cast<int *>(tile) + ((tile_ints + 2 * R + 3) & ~3);   // 16-B aligned
-      const int ktot = A.k[0] * A.k[1] * A.k[2] * A.k[3] * A.cin;
+      const int ktot = A.k[0] * A.k[1] * A.k[2] * A.kt3 * A.cin;
       for (int t = threadIdx.x; t < 4 * A.ns; t += kBlock) {
         const int gq = t / A.ns, st = t - gq * A.ns;
         const int kk = 4 * st + gq;
@@ -291,7 +364,7 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
         if (kk < ktot) {
           int tap = kk / A.cin;
           const int ci = kk - tap * A.cin;
-          const int j3 = tap % A.k[3]; tap /= A.k[3];
+          const int j3 = tap % A.kt3; tap /= A.kt3;
           const int j2 = tap % A.k[2]; tap /= A.k[2];
           const int j1 = tap % A.k[1];
           const int j0 = tap / A.k[1];
@@ -330,7 +403,8 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
 
   // ---- per-lane A-fragment bases: unit -> box coordinates (box dims are powers of two)
   const int g = lane >> 4;                       // k-group of the MFMA fragment
-  const int lb3 = COMPACT ? A.lbox[3] - 1 : A.lbox[3];
+  const bool sh2 = !COMPACT && A.sh2;                 // two-site column packing (NT == 1 launches only)
+  const int lb3 = (COMPACT || sh2) ? A.lbox[3] - 1 : A.lbox[3];
   int abase[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -342,7 +416,7 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
     const int z1 = u & (A.box[1] - 1);
     u >>= A.lbox[1];
     const int z0 = u;
-    int z3 = p3;
+    int z3 = sh2 ? 2 * p3 : p3;
     if (COMPACT) z3 = 2 * p3 + ((A.parity + o[0] + z0 + o[1] + z1 + o[2] + z2) & 1);
     abase[mt] = ((z0 * h1 + z1) * h2 + z2) * h3 + z3 + (A.packed ? 0 : g * A.S);
   }
@@ -370,9 +444,18 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
       mma_packed<T, MT, NT>(A, tile, reinterpret_cast<const int *>(tile) + ((tile_ints + 2 * R + 3) & ~3) + g * A.ns,
                             abase, wf, acc);
     } else {
+      // whole-row pipelining doubles the fragment registers: only where the accumulator tile leaves room
+      // (MT*NT = 12 would exceed 256 VGPR+AGPR and drop to one wave per SIMD)
+      const int rows = ((A.dbg & 4) || MT * NT > 8) ? 0 : A.kt3;
       switch (cc >> 2) {
-        case 1: mma_taps<T, MT, NT, 1>(A, tile, abase, wf, acc, c0 >> 2, 1); break;
-        case 2: mma_taps<T, MT, NT, 2>(A, tile, abase, wf, acc, c0 >> 2, 2); break;
+        case 1: if (rows == 3) mma_rows<T, MT, NT, 1, 3>(A, tile, abase, wf, acc, c0 >> 2);
+                else if (rows == 4) mma_rows<T, MT, NT, 1, 4>(A, tile, abase, wf, acc, c0 >> 2);
+                else mma_taps<T, MT, NT, 1>(A, tile, abase, wf, acc, c0 >> 2, 1);
+                break;
+        case 2: if (rows == 3) mma_rows<T, MT, NT, 2, 3>(A, tile, abase, wf, acc, c0 >> 2);
+                else if (rows == 4) mma_rows<T, MT, NT, 2, 4>(A, tile, abase, wf, acc, c0 >> 2);
+                else mma_taps<T, MT, NT, 2>(A, tile, abase, wf, acc, c0 >> 2, 2);
+                break;
         case 4: mma_taps<T, MT, NT, 4>(A, tile, abase, wf, acc, c0 >> 2, 4); break;
         default: mma_taps<T, MT, NT, 0>(A, tile, abase, wf, acc, c0 >> 2, cc >> 2); break;
       }
@@ -452,6 +535,28 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
     ok = x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2];
     return ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * L3u + x3u;
   };
+  if (sh2) {
+    // columns 0-7: channel co at site 2p; columns 8-15: channel co at site 2p + 1
+    const int co = lane & 7, shift = (lane >> 3) & 1;
+    const T bv = (A.bias && co < A.cout) ? static_cast<const T *>(A.bias)[co] : T(0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int u = ((wave * MT + mt) << 4) + (Mma<T>::kStridedRows ? g + (r << 2) : (g << 2) + r);
+        const int p3 = u & ((1 << lb3) - 1);
+        u >>= lb3;
+        const int z2 = u & (A.box[2] - 1);
+        u >>= A.lbox[2];
+        const int z1 = u & (A.box[1] - 1);
+        u >>= A.lbox[1];
+        const int x0 = o[0] + u, x1 = o[1] + z1, x2 = o[2] + z2, x3 = o[3] + 2 * p3 + shift;
+        if (co < A.cout && x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2] && x3 < A.L[3])
+          out_b[int64_t(co) * Vout + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + x3] =
+              activate(acc[mt][0][r] + bv, A.act);
+      }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     if constexpr (!Mma<T>::kStridedRows) {
@@ -523,6 +628,12 @@ static void launch(const ConvArgs &A, dim3 grid, size_t lds, int fuse, hipStream
 
 using namespace nf;
 
+// 1 if nf_conv_fwd computes this layer with two-site column packing (then the weights must be
+// packed as 16 output columns over k3+1 taps along the fastest axis, see include/normflow_hip.h)
+extern "C" int nf_conv_two_site(int cout, int compact, int l3, int k3) {
+  static const int off = getenv("NF_CONV_NO_TWO_SITE") ? 1 : 0;
+  return !off && cout <= 8 && !compact && l3 % 2 == 0 && l3 >= 4 && (k3 & 1);
+}
 extern "C" int nf_conv_cin_pad(int cin) { return (cin + 3) & ~3; }
 // number of 4-wide reduction steps of the K-packed weight layout (cin % 4 != 0), 0 otherwise
 extern "C" int nf_conv_packed_steps(int cin, int ntaps) {
@@ -566,11 +677,14 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
   A.V = V;
   A.cin = cin; A.cin_pad = (cin + 3) & ~3; A.cout = cout; A.kq = A.cin_pad / 4;
   A.kq_total = A.kq; A.cchunk = A.cin_pad;
+  A.sh2 = (!fz && nf_conv_two_site(cout, compact, A.L[3], A.k[3])) ? 1 : 0;
+  A.kt3 = A.k[3] + A.sh2;
+  if (A.sh2) A.nt_total = 1;
   A.nt_total = (cout + 15) >> 4;
   A.act = act; A.compact = compact ? 1 : 0; A.parity = active_parity & 1;
   A.packed = (cin % 4) != 0 && cin < 8;   // larger odd channel counts: zero-pad to a multiple of 4 and chunk
   if (A.packed) {
-    const int ktot = cin * ksize[0] * ksize[1] * ksize[2] * ksize[3];
+    const int ktot = cin * ksize[0] * ksize[1] * ksize[2] * A.kt3;
     A.ns = ((((ktot + 3) / 4) + 3) / 4) * 4;   // steps of 4 k, rounded up to groups of 4 steps
     A.cin_pad = cin;                           // no channel padding in this mode
     A.kq = 0; A.kq_total = 0; A.cchunk = cin;
@@ -591,11 +705,11 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
   int box[4];
   for (int attempt = 0; attempt < 2; ++attempt) {
     const int units = (kBlock / kWave) * MT * 16;
-    const int target = compact ? 2 * units : units;        // sites in the box
+    const int target = (compact || A.sh2) ? 2 * units : units;        // sites in the box
     int cap[4];
     for (int mu = 0; mu < 4; ++mu) { cap[mu] = 1 << ilog2(A.L[mu]); box[mu] = 1; }
     box[3] = cap[3] < box3_cap ? cap[3] : box3_cap;
-    const int min3 = compact ? 8 : 4;                       // >= 4 units along the fastest axis
+    const int min3 = (compact || A.sh2) ? 8 : 4;            // >= 4 units along the fastest axis
     if (box[3] < min3) box[3] = min3;
     int vol = box[3];
     while (vol < target) {
@@ -635,7 +749,7 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
   // plane stride: odd for the stride-2 reads of compact mode, = 16 mod 32 otherwise, so the
   // four k-groups of an A fragment fall on disjoint LDS banks
   int S = int(halvol);
-  if (compact) S |= 1; else S = ((S + 15) & ~31) + 16;
+  if (compact || A.sh2) S |= 1; else S = ((S + 15) & ~31) + 16;
   A.S = S;
   int64_t rows = 1;
   for (int mu = 0; mu < 3; ++mu) rows *= A.hal[mu];

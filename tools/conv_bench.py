@@ -19,8 +19,7 @@ for name, cin, cout, act, compact in (("L1 1->8 tanh", 1, 8, 1, False), ("L2 8->
     x = torch.randn((B, cin) + lat, device=dev)
     w = 0.1 * torch.randn((cout, cin) + (3,) * len(lat), device=dev)
     b = torch.randn(cout, device=dev)
-    wf = _hip.pack_conv_weight(w)
-    f = lambda: _hip._conv_launch(x, wf, b, w.shape[2:], cout, act, compact, 0)
+    f = lambda: _hip._conv_launch(x, w, b, act, compact, 0)
     for _ in range(2):
         f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
