@@ -220,7 +220,7 @@ __device__ __forceinline__ void mma_rows(const ConvArgs &A, const T *tile, const
     }
   };
   auto request = [&](T (&a)[K3][KQ][MT], T (&b)[K3][KQ][NT]) {
-    const T *__restrict__ wt = wf + (int64_t(row) * K3 * A.kq_total + kq0) * wstep;
+    const T *__restrict__ wt = wf + (int64_t((A.dbg & 8) ? 0 : row) * K3 * A.kq_total + kq0) * wstep;   // dbg 8: L1-resident weights (ablation)
 #pragma unroll
     for (int j3 = 0; j3 < K3; ++j3)
 #pragma unroll
@@ -698,7 +698,7 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
   // the fastest axis (coalescing), then as cubic as the lattice allows (least halo).  MT = 4
   // unless the staged box would then exceed ~80 KiB of LDS (two workgroups per CU keep one
   // staging while the other multiplies); then MT = 2.
-  static const int lds_cap_kb = getenv("NF_CONV_LDS_KB") ? atoi(getenv("NF_CONV_LDS_KB")) : 78;
+  static const int lds_cap_kb = getenv("NF_CONV_LDS_KB") ? atoi(getenv("NF_CONV_LDS_KB")) : 40;
   static const int box3_cap = getenv("NF_CONV_BOX3") ? atoi(getenv("NF_CONV_BOX3")) : 32;
   static const int mt_first = getenv("NF_CONV_MT") ? atoi(getenv("NF_CONV_MT")) : 4;
   int MT = mt_first == 2 ? 2 : 4;
@@ -732,7 +732,8 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
     }
     int64_t hv = 1;
     for (int mu = 0; mu < 4; ++mu) hv *= box[mu] + A.k[mu] - 1;
-    const int cplan = A.packed ? cin : (A.cin_pad < 8 ? A.cin_pad : 8);   // channels planned per K pass
+    static const int cplan_max = getenv("NF_CONV_CPLAN") ? atoi(getenv("NF_CONV_CPLAN")) : 8;
+    const int cplan = A.packed ? cin : (A.cin_pad < cplan_max ? A.cin_pad : cplan_max);   // channels planned per K pass
     if (MT == 2 || hv * cplan * int64_t(sizeof(T)) <= int64_t(lds_cap_kb) * 1024) break;
     MT = 2;
   }
