@@ -1,6 +1,4 @@
 from ._core import Module_, ModuleList_
-from ._core import MultiChannelModule_, MultiOutChannelModule_
-from ._core import InvisibilityMaskWrapperModule_
 
 from .scalar.modules import ConvAct, LinearAct, SplineNet
 from .scalar.convNd import ConvNd, Conv4d

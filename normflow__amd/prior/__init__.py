@@ -1,1 +1,1 @@
-from .prior import Prior, NormalPrior, UniformPrior, PriorList, BlockUpdater
+from .prior import Prior, NormalPrior, UniformPrior

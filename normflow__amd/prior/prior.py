@@ -1,34 +1,45 @@
-"""Prior distributions feeding the flow (reference: src/prior/prior.py)."""
-import copy
+"""Priors: where the flow's input samples and their log-density come from.
+
+API kept from the reference (src/prior/prior.py): `sample(B)`, `sample_(B) -> (x, log r)`,
+`log_prob(x)`, `.to(...)`, `.shape`, `.nvar`, `.parameters`, `.dist`.  The implementation is this
+package's own: a prior is described by two tensors (location / scale, or low / high); samples
+are drawn with the same torch generator calls `torch.distributions` makes (so a seed produces
+the reference's stream), and the normal log-density of device tensors is ONE fused HIP pass
+(`nf_normal_logprob`) instead of log_prob + sum.
+"""
 import math
-from abc import ABC, abstractmethod
 
 import torch
 
 from .. import _hip
 
 
-class Prior(ABC):
-    """Wraps a torch.distributions object: sample(), sample_() -> (x, log r), log_prob()."""
+def _batch_sum(t, keep):
+    """Sum over everything but axis 0 unless densities are propagated."""
+    return t if (keep or t.dim() < 2) else t.flatten(1).sum(dim=1)
+
+
+class Prior:
+    """Two-parameter prior over a lattice of `shape`; subclasses define draw / density."""
 
     propagate_density = False
+    _names = ("a", "b")
 
-    def __init__(self, dist, seed=None):
-        self.dist = dist
-        Prior.manual_seed(seed)
+    def __init__(self, first, second, seed=None):
+        self._p = [first, second]
+        self.shape = tuple(first.shape)
+        self.manual_seed(seed)
 
+    # -- protocol
     def sample(self, batch_size=1):
-        return self.dist.sample((batch_size,))
+        return self._draw((batch_size,) + self.shape)
 
     def sample_(self, batch_size=1):
         x = self.sample(batch_size)
         return x, self.log_prob(x)
 
     def log_prob(self, x):
-        dens = self.dist.log_prob(x)
-        if self.propagate_density or dens.dim() < 2:
-            return dens
-        return dens.sum(dim=tuple(range(1, dens.dim())))
+        return _batch_sum(self._density(x), self.propagate_density)
 
     @staticmethod
     def manual_seed(seed):
@@ -39,112 +50,78 @@ class Prior(ABC):
     def nvar(self):
         return math.prod(self.shape)
 
-    @abstractmethod
     def to(self, *args, **kwargs):
-        """Move the distribution's parameters (and hence its samples) to a device/dtype."""
-
-    @property
-    @abstractmethod
-    def parameters(self):
-        """dict of the tensors defining the prior."""
-
-
-class UniformPrior(Prior):
-    """Uniform on [low, high] (prior.py:65-91)."""
-
-    def __init__(self, low=None, high=None, shape=None, seed=None, **kwargs):
-        if shape is not None:
-            low, high = torch.zeros(shape), torch.ones(shape)
-        else:
-            shape = low.shape
-        super().__init__(torch.distributions.uniform.Uniform(low, high), seed, **kwargs)
-        self.shape = shape
-
-    def to(self, *args, **kwargs):
-        self.dist.low = self.dist.low.to(*args, **kwargs)
-        self.dist.high = self.dist.high.to(*args, **kwargs)
+        """Move the defining tensors (and hence future samples) to a device / dtype."""
+        self._p = [t.to(*args, **kwargs) for t in self._p]
 
     @property
     def parameters(self):
-        return dict(low=self.dist.low, high=self.dist.high)
+        return dict(zip(self._names, self._p))
+
+    def _draw(self, full_shape):
+        raise NotImplementedError
+
+    def _density(self, x):
+        raise NotImplementedError
 
 
 class NormalPrior(Prior):
-    """Normal(loc, scale); shape=... gives a unit normal on that lattice (prior.py:92-125).
-    On the device the per-sample log-density is ONE fused pass (nf_normal_logprob)."""
+    """Independent normals; `shape=L` means zero mean, unit width on that lattice."""
 
-    def log_prob(self, x):
-        loc, scale = self.dist.loc, self.dist.scale
-        if (not self.propagate_density and _hip.endpoint_supported(x) and x.dim() >= 2
-                and tuple(x.shape[1:]) == tuple(loc.shape) and loc.device == x.device and loc.dtype == x.dtype):
-            return _hip.NormalLogProbFn.apply(x, loc.contiguous(), scale.contiguous())
-        return super().log_prob(x)
+    _names = ("loc", "scale")
 
-    def __init__(self, loc=None, scale=None, shape=None, seed=None, **kwargs):
+    def __init__(self, loc=None, scale=None, shape=None, seed=None):
         if shape is not None:
             loc, scale = torch.zeros(shape), torch.ones(shape)
-        else:
-            shape = loc.shape
-        super().__init__(torch.distributions.normal.Normal(loc, scale), seed, **kwargs)
-        self.shape = shape
+        super().__init__(loc, scale, seed)
 
-    def setup_blockupdater(self, block_len):
-        chopped = NormalPrior(loc=self.dist.loc.ravel()[:block_len], scale=self.dist.scale.ravel()[:block_len])
-        self.blockupdater = BlockUpdater(chopped, block_len)
-
-    def to(self, *args, **kwargs):
-        self.dist.loc = self.dist.loc.to(*args, **kwargs)
-        self.dist.scale = self.dist.scale.to(*args, **kwargs)
+    loc = property(lambda self: self._p[0])
+    scale = property(lambda self: self._p[1])
 
     @property
-    def parameters(self):
-        return dict(loc=self.dist.loc, scale=self.dist.scale)
+    def dist(self):
+        """The equivalent torch.distributions object (reference attribute)."""
+        return torch.distributions.normal.Normal(self.loc, self.scale)
 
+    def _draw(self, full_shape):
+        with torch.no_grad():      # what Normal.sample does: one torch.normal on expanded parameters
+            return torch.normal(self.loc.expand(full_shape), self.scale.expand(full_shape))
 
-class PriorList:
-    """A list of priors sampled together (prior.py:128-157)."""
-
-    def __init__(self, prior_list):
-        self.prior_list = prior_list
-
-    def sample(self, batch_size=1):
-        return [p.sample(batch_size) for p in self.prior_list]
-
-    def sample_(self, batch_size=1):
-        x = self.sample(batch_size)
-        return x, self.log_prob(x)
+    def _density(self, x):
+        z = (x - self.loc) / self.scale
+        return -0.5 * z * z - torch.log(self.scale) - 0.5 * math.log(2 * math.pi)
 
     def log_prob(self, x):
-        return [p.log_prob(xi) for p, xi in zip(self.prior_list, x)]
+        fused = (not self.propagate_density and x.dim() >= 2 and _hip.endpoint_supported(x)
+                 and tuple(x.shape[1:]) == self.shape and self.loc.device == x.device
+                 and self.loc.dtype == x.dtype)
+        if fused:
+            return _hip.NormalLogProbFn.apply(x, self.loc.contiguous(), self.scale.contiguous())
+        return super().log_prob(x)
+
+
+class UniformPrior(Prior):
+    """Independent uniforms on [low, high); `shape=L` means the unit interval."""
+
+    _names = ("low", "high")
+
+    def __init__(self, low=None, high=None, shape=None, seed=None):
+        if shape is not None:
+            low, high = torch.zeros(shape), torch.ones(shape)
+        super().__init__(low, high, seed)
+
+    low = property(lambda self: self._p[0])
+    high = property(lambda self: self._p[1])
 
     @property
-    def nvar(self):
-        return sum(p.nvar for p in self.prior_list)
+    def dist(self):
+        return torch.distributions.uniform.Uniform(self.low, self.high)
 
-    def to(self, *args, **kwargs):
-        for p in self.prior_list:
-            p.to(*args, **kwargs)
+    def _draw(self, full_shape):
+        with torch.no_grad():
+            u = torch.rand(full_shape, dtype=self.low.dtype, device=self.low.device)
+            return self.low + u * (self.high - self.low)
 
-    @property
-    def parameters(self):
-        return [p.parameters for p in self.prior_list]
-
-
-class BlockUpdater:
-    """In-place refresh of one block of variables, with undo (prior.py:160-178)."""
-
-    def __init__(self, chopped_prior, block_len):
-        self.block_len = block_len
-        self.chopped_prior = chopped_prior
-        self.backup_block = None
-
-    def _blocks(self, x):
-        return x.view(x.shape[0], -1, self.block_len)
-
-    def __call__(self, x, block_ind):
-        view = self._blocks(x)
-        self.backup_block = copy.deepcopy(view[:, block_ind])
-        view[:, block_ind] = self.chopped_prior.sample(x.shape[0])
-
-    def restore(self, x, block_ind, restore_ind=slice(None)):
-        self._blocks(x)[restore_ind, block_ind] = self.backup_block[restore_ind]
+    def _density(self, x):
+        inside = (x >= self.low) & (x < self.high)
+        return torch.where(inside, -torch.log(self.high - self.low), torch.full_like(x, -math.inf))
