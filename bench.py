@@ -181,10 +181,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the hot path)"
-    dev = torch.device("cuda", local)
+    # NF_BENCH_REHEARSAL=1: dry run of the multi-rank code path on a box with fewer GPUs than ranks
+    # (all ranks share cuda:0, gloo instead of RCCL).  Never used for reported numbers.
+    rehearsal = os.environ.get("NF_BENCH_REHEARSAL", "0") == "1"
+    dev = torch.device("cuda", 0 if rehearsal else local)
     torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # RCCL
+        dist.init_process_group(backend="gloo" if rehearsal else "nccl", rank=rank, world_size=world)   # "nccl" = RCCL
     import normflow__amd  # noqa: F401
     lattice = tuple(int(s) for s in a.lattice.split(","))
     net_, cpl = build_net(lattice, a.layers, a.knots, dev, seed=2024)       # same weights on all ranks
@@ -208,7 +211,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert bool(torch.isfinite(logJ).all()) and bool(torch.isfinite(y).all())
