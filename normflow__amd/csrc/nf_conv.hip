@@ -23,6 +23,7 @@
 //   * epilogue: bias, activation, store as channel planes (B, Cout, V) -- the layout torch
 //     uses, so the kernel drops in for the torch convolution -- or, in pair-compact mode,
 //     only the ACTIVE site of every aligned site pair, to (B, Cout, V/2).
+#include <cstdio>
 #include <cstdlib>
 #include "nf_rqs_core.h"
 
@@ -72,6 +73,7 @@ struct ConvArgs {
   double *partial;      // (B, gridDim.x) per-workgroup log-det partials
   RqsParams P;
   int packed, ns;       // packed: K = (tap, ci) flattened, 4 per step, ns steps (multiple of 4)
+  unsigned long long *stamps;   // diagnostic build only (NF_CONV_STAMPS): 8 clock stamps per workgroup
   int dbg;              // profiling ablation (NF_CONV_DBG): bit0 skip staging, bit1 skip the MFMA loop
 };
 
@@ -198,8 +200,8 @@ __device__ __forceinline__ void mma_taps(const ConvArgs &A, const T *tile, const
 // 3*KQ*MT*NT MFMAs instead of once per KQ*MT*NT.
 template <typename T, int MT, int NT, int KQ, int K3>
 __device__ __forceinline__ void mma_rows(const ConvArgs &A, const T *tile, const int (&abase)[MT],
-                                          const T *__restrict__ wf, typename Mma<T>::vec4 (&acc)[MT][NT],
-                                          int kq0) {
+                                         const T *__restrict__ wf, typename Mma<T>::vec4 (&acc)[MT][NT],
+                                         int kq0) {
   const int nrows = A.k[0] * A.k[1] * A.k[2];
   const int wstep = A.nt_total << 6;
   const int S4 = 4 * A.S;
@@ -246,21 +248,24 @@ __device__ __forceinline__ void mma_rows(const ConvArgs &A, const T *tile, const
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Mma<T>::mma(a[j3][q][mt], b[j3][q][nt], acc[mt][nt]);
   };
+  // Rows are taken in pairs inside ONE basic block (no branch between a request and the multiply it
+  // overlaps with: a conditional there let the optimizer sink the prefetch loads to their use and
+  // exposed a full L2 latency per row); an odd last row is peeled off after the loop.
   request(a0, b0);
-  for (int r = 0; r < nrows; r += 2) {
+  int r = 0;
+  for (; r + 1 < nrows; r += 2) {
     next();
     request(a1, b1);
     __builtin_amdgcn_sched_barrier(0);
     multiply(a0, b0);
     __builtin_amdgcn_sched_barrier(0);
-    if (r + 1 < nrows) {
-      next();
-      request(a0, b0);
-      __builtin_amdgcn_sched_barrier(0);
-      multiply(a1, b1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    next();
+    request(a0, b0);                                    // (clamped re-read when r + 2 == nrows)
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
   }
+  if (r < nrows) multiply(a0, b0);
 }
 
 // K-packed variant for cin % 4 != 0 (e.g. the 1 -> 8 first layer of ConvAct): the reduction
@@ -312,8 +317,18 @@ __device__ __forceinline__ void mma_packed(const ConvArgs &A, const T *tile, con
   }
 }
 
+__device__ __forceinline__ void stamp(const ConvArgs &A, int slot) {
+  if (A.stamps && threadIdx.x == 0) {
+    const unsigned id = blockIdx.y * gridDim.x + blockIdx.x;
+    if (id < 4096u) A.stamps[id * 8 + slot] = __builtin_readcyclecounter();
+  }
+}
+
+// Register budget: the fp32 MT=2 variants are asked to fit 3 waves per SIMD (<= 168 VGPR+AGPR, no spills);
+// left alone the allocator takes 201 registers for the 8->46 kernel and only 2 workgroups fit a CU
+// (census by HW_ID: 1.78 resident workgroups per CU), which starves the matrix pipe during staging.
 template <typename T, int MT, int NT, bool COMPACT, int FUSE>
-__global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
+__global__ __launch_bounds__(kBlock, (sizeof(T) == 4 && MT == 2) ? 3 : 2) void conv_kernel(ConvArgs A) {
   static_assert(FUSE == 0 || sizeof(T) == 4, "the fused coupling epilogue is fp32 only");
   typedef typename Mma<T>::vec4 acc_t;
   extern __shared__ __align__(16) unsigned char smem_conv[];
@@ -322,6 +337,16 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int nwaves = kBlock / kWave;
+  stamp(A, 0);
+  if (A.stamps && threadIdx.x == 0) {     // diagnostic: which CU hosts this workgroup
+    const unsigned id = blockIdx.y * gridDim.x + blockIdx.x;
+    if (id < 4096u) {
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      A.stamps[id * 8 + 7] = ((unsigned long long)(xcc & 0xf) << 16) | ((hw >> 8) & 0xff);   // xcc | se,sh,cu
+    }
+  }
   // ---- which box
   int bid = blockIdx.x;
   int o[4];
@@ -383,20 +408,40 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
       const int z3 = z3b + lane;
       const bool in_row = z3 < h3;
       const int x3 = wrap(o[3] + z3 - r3, A.L[3]);
-      for (int r = wave; r < R; r += nwaves) {
-        const int src = rowsrc[r] + x3, dst = rowdst[r] + z3;
-        const T *__restrict__ pl = in_b + int64_t(c0) * A.V + src;
+      // RG rows x 4 channels = 16 independent loads in flight per wave before the first LDS
+      // store (4 in flight left the copy latency-bound: ~300 cycles per load, measured by stamps)
+      constexpr int RG = 4;
+      for (int r0 = wave; r0 < R; r0 += nwaves * RG) {
+        int src[RG], dst[RG];
+#pragma unroll
+        for (int j = 0; j < RG; ++j) {
+          const int r = r0 + j * nwaves;
+          const int rr = r < R ? r : r0;                 // clamp (harmless duplicate of row r0)
+          src[j] = rowsrc[rr] + x3;
+          dst[j] = r < R ? rowdst[rr] + z3 : -1;
+        }
         int c = 0;
         for (; c + 4 <= creal; c += 4) {
-          T v[4];
+          T v[RG][4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = in_row ? pl[int64_t(c + i) * A.V] : T(0);
+          for (int j = 0; j < RG; ++j)
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (in_row) tile[(c + i) * A.S + dst] = v[i];
+            for (int i = 0; i < 4; ++i)
+              v[j][i] = in_row ? in_b[int64_t(c0 + c + i) * A.V + src[j]] : T(0);
+#pragma unroll
+          for (int j = 0; j < RG; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (in_row && dst[j] >= 0) tile[(c + i) * A.S + dst[j]] = v[j][i];
         }
-        for (; c < creal; ++c)
-          if (in_row) tile[c * A.S + dst] = pl[int64_t(c) * A.V];
+        for (; c < creal; ++c) {
+          T v[RG];
+#pragma unroll
+          for (int j = 0; j < RG; ++j) v[j] = in_row ? in_b[int64_t(c0 + c) * A.V + src[j]] : T(0);
+#pragma unroll
+          for (int j = 0; j < RG; ++j)
+            if (in_row && dst[j] >= 0) tile[c * A.S + dst[j]] = v[j];
+        }
       }
     }
   };
@@ -437,8 +482,10 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
   for (int c0 = 0; c0 < A.cin_pad; c0 += A.cchunk) {
     const int cc = A.cin_pad - c0 < A.cchunk ? A.cin_pad - c0 : A.cchunk;
     if (c0) __syncthreads();                            // every wave is done reading the previous chunk
+    stamp(A, c0 ? 3 : 1);
     stage(c0, cc);
     __syncthreads();
+    stamp(A, c0 ? 4 : 2);
     if (A.dbg & 2) continue;
     if (A.packed) {
       mma_packed<T, MT, NT>(A, tile, reinterpret_cast<const int *>(tile) + ((tile_ints + 2 * R + 3) & ~3) + g * A.ns,
@@ -462,6 +509,7 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
     }
   }
 
+  stamp(A, 5);
   // ---- fused coupling epilogue (FUSE = 1 forward, 2 inverse): accumulators (+bias) -> LDS as
   // [channel][unit] -> one lane per ACTIVE site runs the RQ-spline map on its 3M-2 logits ->
   // y pair store + per-workgroup log-det partial.  The (B, C, V/2) logit tensor is never
@@ -514,6 +562,7 @@ __global__ __launch_bounds__(kBlock) void conv_kernel(ConvArgs A) {
     }
     const double tot = block_sum(lacc, red);
     if (threadIdx.x == 0) A.partial[int64_t(b) * gridDim.x + blockIdx.x] = tot;
+    stamp(A, 6);
     return;
   }
 
@@ -767,6 +816,10 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
     const size_t stage = size_t(48) * ((kBlock / kWave) * MT * 16 + 4) * sizeof(float);
     if (lds < stage) lds = stage;
   }
+  {
+    static const int pad_kb = getenv("NF_CONV_LDS_PAD_KB") ? atoi(getenv("NF_CONV_LDS_PAD_KB")) : 0;   // occupancy experiments
+    lds += size_t(pad_kb) * 1024;
+  }
   NF_REQUIRE(lds <= 160 * 1024, "nf_conv_fwd: input box needs %zu B of LDS (> 160 KiB): cin=%d, kernel %dx%dx%dx%d",
              lds, cin, A.k[0], A.k[1], A.k[2], A.k[3]);
   NF_REQUIRE(nblocks <= 0x7fffffff, "nf_conv_fwd: lattice too large");
@@ -783,6 +836,13 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
     }
     *fz->blocks_out = nblocks;
   }
+  static const int want_stamps = getenv("NF_CONV_STAMPS") ? atoi(getenv("NF_CONV_STAMPS")) : 0;
+  unsigned long long *d_stamps = nullptr;
+  if (want_stamps) {      // DIAGNOSTIC ONLY: allocates and synchronises, never enabled in product use
+    (void)hipMalloc(&d_stamps, 4096 * 8 * sizeof(unsigned long long));
+    (void)hipMemset(d_stamps, 0, 4096 * 8 * sizeof(unsigned long long));
+    A.stamps = d_stamps;
+  }
   for (int nt0 = 0; nt0 < A.nt_total; nt0 += 3) {
     A.nt0 = nt0;
     const int n = A.nt_total - nt0 >= 3 ? 3 : A.nt_total - nt0;
@@ -797,6 +857,45 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
     }
     const int rc = check_launch("conv kernel");
     if (rc) return rc;
+  }
+  if (want_stamps) {
+    (void)hipStreamSynchronize(stream);
+    static unsigned long long h[4096 * 8];
+    (void)hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d_stamps);
+    double seg[6] = {0, 0, 0, 0, 0, 0};
+    int n = 0;
+    for (int i = 1024; i < 4096; ++i) {     // skip the first dispatch round
+      const unsigned long long *t = h + i * 8;
+      if (!t[0] || !t[5]) continue;
+      ++n;
+      seg[0] += double(t[1] - t[0]); seg[1] += double(t[2] - t[1]);
+      seg[2] += t[3] ? double(t[3] - t[2]) : double(t[5] - t[2]);
+      seg[3] += t[3] ? double(t[4] - t[3]) : 0.0;
+      seg[4] += t[3] ? double(t[5] - t[4]) : 0.0;
+      seg[5] += t[6] ? double(t[6] - t[5]) : 0.0;
+    }
+    {
+      // mean number of co-resident workgroups per CU (per-CU windows: clock counters differ between XCDs)
+      static double busy[16 * 256];
+      static unsigned long long lo[16 * 256], hi[16 * 256];
+      for (int k = 0; k < 16 * 256; ++k) { busy[k] = 0; lo[k] = ~0ull; hi[k] = 0; }
+      for (int i = 0; i < 4096; ++i) {
+        const unsigned long long *t = h + i * 8;
+        const unsigned long long end = t[6] ? t[6] : t[5];
+        if (!t[0] || !end) continue;
+        const int key = int(((t[7] >> 16) & 0xf) * 256 + (t[7] & 0xff));
+        busy[key] += double(end - t[0]);
+        if (t[0] < lo[key]) lo[key] = t[0];
+        if (end > hi[key]) hi[key] = end;
+      }
+      double conc = 0; int cus = 0;
+      for (int k = 0; k < 16 * 256; ++k)
+        if (hi[k] > lo[k]) { conc += busy[k] / double(hi[k] - lo[k]); ++cus; }
+      if (cus) fprintf(stderr, "[nf_conv stamps] %d CUs seen, mean co-resident workgroups per CU (first 4096 workgroups) %.2f\n", cus, conc / cus);
+    }
+    if (n) fprintf(stderr, "[nf_conv stamps] cin=%d cout=%d compact=%d fuse=%d blocks=%d | cycles: prologue %.0f  stage0 %.0f  mma0 %.0f  stage1 %.0f  mma1 %.0f  epilogue %.0f\n",
+                   cin, cout, compact, fuse, n, seg[0] / n, seg[1] / n, seg[2] / n, seg[3] / n, seg[4] / n, seg[5] / n);
   }
   return NF_OK;
 }
