@@ -194,6 +194,22 @@ int nf_conv_packed_steps(int cin, int ntaps);
 int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, void *out, int64_t B,
                 const int32_t *lattice, const int32_t *ksize, int cin, int cout, int act,
                 int compact, int active_parity, int dtype, void *stream);
+/* Weight layout nf_conv_fwd / nf_conv_rqs (fused != 0) expects for this layer; pure planning, no GPU work.
+ *   NF_WLAYOUT_FRAGMENT (0): the fragment order above, [tap][cin_pad/4][ntiles][4][16];
+ *   NF_WLAYOUT_ROWPACK  (1): [row][cin_pad/4][64][NV], row = the taps of all axes but the fastest (row-major),
+ *       lane = 16*(channel within the quad) + (column within its tile), value index v = j3*ntiles + tile for
+ *       tap j3 < K3 along the fastest axis (K3 = k3, or k3 + 1 with two-site packing), NV = K3*ntiles rounded
+ *       up to a multiple of 4 (zero fill).  I.e. fragment order permuted so that everything a lane needs for one
+ *       kernel row sits in NV/4 16-byte words.  Used by the persistent kernel (fp32, cin % 4 == 0, k3 == 3,
+ *       <= 48 output columns).
+ * Returns the code, or -1 for invalid arguments. */
+enum { NF_WLAYOUT_FRAGMENT = 0, NF_WLAYOUT_ROWPACK = 1 };
+int nf_conv_weight_layout(const int32_t *lattice, const int32_t *ksize, int cin, int cout, int compact,
+                          int fused, int dtype);
+/* Which kernel the calling thread's last nf_conv_fwd / nf_conv_rqs launched: 0 = one box per workgroup
+ * (nf_conv.hip), 1 = persistent workgroups with staging overlapped with the MFMAs (nf_conv_pipe.hip;
+ * fp32, cin % 4 == 0, kernel extent 3 on the fastest axis).  Same results either way; for tests and benches. */
+int nf_conv_last_path(void);
 
 /* ---- K5+K2 fused: last conv layer of the parameter net + RQ-spline coupling ---------------
  * The (B, 3m-2, V/2) logit tensor is produced in the MFMA accumulators, staged in LDS and

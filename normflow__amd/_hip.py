@@ -62,6 +62,8 @@ PROTOTYPES = {
     "nf_conv_wgrad_cols": (_I, [_I, _I]),
     "nf_conv_wgrad": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I, _P]),
     "nf_conv_rqs_supported": (_I, [_I, _I]),
+    "nf_conv_last_path": (_I, []),
+    "nf_conv_weight_layout": (_I, [_P, _P, _I, _I, _I, _I, _I]),
     "nf_conv_rqs": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I,
                          C.POINTER(RqsOpts), _I, _P, _SZ, _I, _P]),
     "nf_conv_fwd": (_I, [_P, _P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I, _I, _I,
@@ -400,6 +402,26 @@ def pack_conv_weight(w):
     return wp.reshape(nt, 16, cin_pad // 4, 4, ntaps).permute(4, 2, 0, 3, 1).contiguous()
 
 
+def conv_weight_for_layer(w, lat4, k4, cin, cout, compact, fused, dtype_code):
+    """Pack (Cout', Cin, *k) weights (already two-site expanded where that applies) in the layout the
+    library will read for this layer (nf_conv_weight_layout): fragment order, or row-packed for the
+    persistent kernel -- [row][cin/4][lane][K3*ntiles -> multiple of 4]."""
+    frag = pack_conv_weight(w)
+    code = load().nf_conv_weight_layout(lat4, k4, cin, cout, int(compact), int(fused), dtype_code)
+    if code < 0:
+        raise RuntimeError("nf_conv_weight_layout: invalid layer description")
+    if code == 0:
+        return frag
+    ntaps, kq, nt = frag.shape[:3]
+    k3 = w.shape[-1]
+    rows = ntaps // k3
+    vals = frag.reshape(rows, k3, kq, nt, 64).permute(0, 2, 4, 1, 3).reshape(rows, kq, 64, k3 * nt)
+    nv = (k3 * nt + 3) // 4 * 4
+    out = vals.new_zeros(rows, kq, 64, nv)
+    out[..., :k3 * nt] = vals
+    return out.contiguous()
+
+
 def conv_supported(x, weight):
     return (x.is_cuda and x.dtype in (torch.float32, torch.float64) and weight.dtype == x.dtype
             and 1 <= x.dim() - 2 <= 4)
@@ -421,9 +443,9 @@ def _conv_launch(x, weight, bias, act, compact, parity):
         w2 = weight.new_zeros((16, cin) + tuple(ksize[:-1]) + (ksize[-1] + 1,))
         w2[:cout, ..., :ksize[-1]] = weight
         w2[8:8 + cout, ..., 1:] = weight
-        wfrag = pack_conv_weight(w2)
+        wfrag = conv_weight_for_layer(w2, lat4, k4, cin, cout, compact, False, _dtype_code(x))
     else:
-        wfrag = pack_conv_weight(weight)
+        wfrag = conv_weight_for_layer(weight, lat4, k4, cin, cout, compact, False, _dtype_code(x))
     V = 1
     for n in lat:
         V *= n
@@ -545,7 +567,7 @@ def conv_rqs(h, weight, bias, x_active, log0, parity, opts, inverse):
     lat4 = (C.c_int32 * 4)(*([1] * (4 - d) + lat))
     k4 = (C.c_int32 * 4)(*([1] * (4 - d) + list(weight.shape[2:])))
     V = x_active.shape[1]
-    wfrag = pack_conv_weight(weight.detach())
+    wfrag = conv_weight_for_layer(weight.detach(), lat4, k4, cin, weight.shape[0], True, True, NF_F32)
     bias = None if bias is None else bias.detach().contiguous()
     y = torch.empty_like(x_active)
     logj = torch.empty(B, dtype=x_active.dtype, device=x_active.device)

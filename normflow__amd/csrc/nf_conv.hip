@@ -25,109 +25,9 @@
 //     only the ACTIVE site of every aligned site pair, to (B, Cout, V/2).
 #include <cstdio>
 #include <cstdlib>
-#include "nf_rqs_core.h"
+#include "nf_conv_core.h"
 
 namespace nf {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-
-// The 16x16x4 matrix-core instruction per element type.  A: lane l holds A[row l&15][k l>>4];
-// B: B[k l>>4][col l&15]; C/D: col = l&15 and, for f32, rows 4(l>>4)+r, for f64 rows (l>>4)+4r
-// (cdna_hip_programming.md section 3: "f64 MFMA does NOT use these maps").
-template <typename T> struct Mma;
-template <> struct Mma<float> {
-  typedef f32x4 vec4;
-  static constexpr bool kStridedRows = false;
-  static __device__ __forceinline__ vec4 mma(float a, float b, vec4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-  }
-};
-template <> struct Mma<double> {
-  typedef f64x4 vec4;
-  static constexpr bool kStridedRows = true;
-  static __device__ __forceinline__ vec4 mma(double a, double b, vec4 c) {
-    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-  }
-};
-
-enum { kActNone = 0, kActTanh = 1, kActRelu = 2, kActLeakyRelu = 3, kActSoftplus = 4, kActAbs = 5,
-       kActSigmoid = 6 };
-
-struct ConvArgs {
-  const void *in;       // (B, Cin, V) of T
-  const void *wfrag;    // [tap][kq][ntile][64] fragment-ordered, zero padded, of T
-  const void *bias;     // (Cout) of T, or null
-  void *out;            // (B, Cout, V) or (B, Cout, V/2) of T
-  int64_t V;
-  int L[4], k[4], box[4], lbox[4], nbox[4], hal[4];
-  int S;                // LDS plane stride (dwords)
-  int cin, cin_pad, cout, kq, nt_total, nt0;
-  int kt3;              // taps walked along the fastest axis: k[3], or k[3]+1 in two-site mode
-  int sh2;              // two-site column packing (cout <= 8): cols 0-7 -> site 2p, cols 8-15 -> site 2p+1
-  int cchunk, kq_total;  // channels staged per pass of the K loop (multiple of 4); cin_pad / 4
-  int act, compact, parity;
-  // fused coupling epilogue (nf_conv_rqs): the logits never leave the CU
-  const float *xact;    // (B, V) field, active sites are transformed
-  float *yout;          // (B, V) out: value at active sites, 0 at frozen sites
-  double *partial;      // (B, gridDim.x) per-workgroup log-det partials
-  RqsParams P;
-  int packed, ns;       // packed: K = (tap, ci) flattened, 4 per step, ns steps (multiple of 4)
-  unsigned long long *stamps;   // diagnostic build only (NF_CONV_STAMPS): 8 clock stamps per workgroup
-  int dbg;              // profiling ablation (NF_CONV_DBG): bit0 skip staging, bit1 skip the MFMA loop
-};
-
-__device__ __forceinline__ float activate(float v, int act) {
-  switch (act) {
-    case kActTanh: return tanhf(v);
-    case kActRelu: return v > 0.f ? v : 0.f;
-    case kActLeakyRelu: return v > 0.f ? v : 0.01f * v;
-    case kActSoftplus: return v > 20.f ? v : log1pf(expf(v));
-    case kActAbs: return fabsf(v);
-    case kActSigmoid: return 1.f / (1.f + expf(-v));
-    default: return v;
-  }
-}
-__device__ __forceinline__ double activate(double v, int act) {
-  switch (act) {
-    case kActTanh: return tanh(v);
-    case kActRelu: return v > 0. ? v : 0.;
-    case kActLeakyRelu: return v > 0. ? v : 0.01 * v;
-    case kActSoftplus: return v > 20. ? v : log1p(exp(v));
-    case kActAbs: return fabs(v);
-    case kActSigmoid: return 1. / (1. + exp(-v));
-    default: return v;
-  }
-}
-
-__device__ __forceinline__ int wrap(int v, int L) {
-  v %= L;
-  return v < 0 ? v + L : v;
-}
-
-// Tap counters (uniform): row-major walk over the kernel window; `off` is the LDS offset of
-// the tap relative to a unit's own position in the staged tile.
-struct TapWalk {
-  int j1, j2, j3, off, tap;
-  __device__ __forceinline__ void next(const ConvArgs &A, int ntaps) {
-    if (tap + 1 >= ntaps) return;               // clamp at the last tap (harmless re-read)
-    ++tap;
-    const int h3 = A.hal[3], h2 = A.hal[2], h1 = A.hal[1];
-    ++off;
-    if (++j3 == A.kt3) {
-      j3 = 0;
-      off += h3 - A.kt3;
-      if (++j2 == A.k[2]) {
-        j2 = 0;
-        off += (h2 - A.k[2]) * h3;
-        if (++j1 == A.k[1]) {
-          j1 = 0;
-          off += (h1 - A.k[1]) * h2 * h3;
-        }
-      }
-    }
-  }
-};
 
 template <typename T, int MT, int NT, int KQ>
 __device__ __forceinline__ void mma_taps(const ConvArgs &A, const T *tile, const int (&abase)[MT],
@@ -317,13 +217,6 @@ __device__ __forceinline__ void mma_packed(const ConvArgs &A, const T *tile, con
   }
 }
 
-__device__ __forceinline__ void stamp(const ConvArgs &A, int slot) {
-  if (A.stamps && threadIdx.x == 0) {
-    const unsigned id = blockIdx.y * gridDim.x + blockIdx.x;
-    if (id < 4096u) A.stamps[id * 8 + slot] = __builtin_readcyclecounter();
-  }
-}
-
 // Register budget: the fp32 MT=2 variants are asked to fit 3 waves per SIMD (<= 168 VGPR+AGPR, no spills);
 // left alone the allocator takes 201 registers for the 8->46 kernel and only 2 workgroups fit a CU
 // (census by HW_ID: 1.78 resident workgroups per CU), which starves the matrix pipe during staging.
@@ -510,143 +403,8 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 && MT == 2) ? 3 : 2) void c
   }
 
   stamp(A, 5);
-  // ---- fused coupling epilogue (FUSE = 1 forward, 2 inverse): accumulators (+bias) -> LDS as
-  // [channel][unit] -> one lane per ACTIVE site runs the RQ-spline map on its 3M-2 logits ->
-  // y pair store + per-workgroup log-det partial.  The (B, C, V/2) logit tensor is never
-  // written to or read from HBM.
-  if constexpr (FUSE > 0) {
-    constexpr int M = NT == 1 ? 4 : (NT == 2 ? 8 : 16);
-    constexpr int C = 3 * M - 2;
-    constexpr int UNITS = (kBlock / kWave) * MT * 16;
-    constexpr int PU = UNITS + 4;                       // row pitch: 16-B aligned rows
-    __syncthreads();                                    // the input tile is dead from here on
-    float *pt = reinterpret_cast<float *>(tile);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int co = (nt << 4) + (lane & 15);
-        const float bv = (A.bias && co < A.cout) ? static_cast<const float *>(A.bias)[co] : 0.f;
-        acc_t v = acc[mt][nt];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += bv;
-        *reinterpret_cast<acc_t *>(reinterpret_cast<T *>(pt) + co * PU + ((wave * MT + mt) << 4) + (g << 2)) = v;
-      }
-    __syncthreads();
-    double lacc = 0.0;
-    if (threadIdx.x < UNITS) {
-      int u = threadIdx.x;
-      const int p3 = u & ((1 << lb3) - 1);
-      u >>= lb3;
-      const int z2 = u & (A.box[2] - 1);
-      u >>= A.lbox[2];
-      const int z1 = u & (A.box[1] - 1);
-      u >>= A.lbox[1];
-      const int z0 = u;
-      const int x0 = o[0] + z0, x1 = o[1] + z1, x2 = o[2] + z2, x3p = o[3] / 2 + p3;
-      if (x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2] && x3p < A.L[3] / 2) {
-        const int off = (A.parity + x0 + x1 + x2) & 1;  // which site of the pair is active
-        const int64_t pair = int64_t(b) * (A.V / 2) + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * (A.L[3] / 2) + x3p;
-        const float2 xv = reinterpret_cast<const float2 *>(A.xact)[pair];
-        RegCol<float, C> a;
-#pragma unroll
-        for (int c = 0; c < C; ++c) a[c] = pt[c * PU + threadIdx.x];
-        float val, logd;
-        rqs_site<float, M, FUSE == 2>(a, A.P, off ? xv.y : xv.x, val, logd);
-        float2 ov;
-        ov.x = off ? 0.f : val;
-        ov.y = off ? val : 0.f;
-        reinterpret_cast<float2 *>(A.yout)[pair] = ov;
-        lacc = double(logd);
-      }
-    }
-    const double tot = block_sum(lacc, red);
-    if (threadIdx.x == 0) A.partial[int64_t(b) * gridDim.x + blockIdx.x] = tot;
-    stamp(A, 6);
-    return;
-  }
-
-  // ---- epilogue: C/D layout  col = lane&15 (channel); rows (sites) 4*(lane>>4)+r for f32,
-  // (lane>>4)+4r for f64
-  const int64_t Vout = COMPACT ? A.V / 2 : A.V;
-  T *__restrict__ out_b = static_cast<T *>(A.out) + int64_t(b) * A.cout * Vout;
-  const int L3u = COMPACT ? A.L[3] / 2 : A.L[3];
-  auto unit_base = [&](int u, int &x3u, bool &ok) -> int64_t {   // unit -> offset in an output plane
-    const int p3 = u & ((1 << lb3) - 1);
-    u >>= lb3;
-    const int z2 = u & (A.box[2] - 1);
-    u >>= A.lbox[2];
-    const int z1 = u & (A.box[1] - 1);
-    u >>= A.lbox[1];
-    const int z0 = u;
-    const int x0 = o[0] + z0, x1 = o[1] + z1, x2 = o[2] + z2;
-    x3u = (COMPACT ? o[3] / 2 : o[3]) + p3;
-    ok = x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2];
-    return ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * L3u + x3u;
-  };
-  if (sh2) {
-    // columns 0-7: channel co at site 2p; columns 8-15: channel co at site 2p + 1
-    const int co = lane & 7, shift = (lane >> 3) & 1;
-    const T bv = (A.bias && co < A.cout) ? static_cast<const T *>(A.bias)[co] : T(0);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int u = ((wave * MT + mt) << 4) + (Mma<T>::kStridedRows ? g + (r << 2) : (g << 2) + r);
-        const int p3 = u & ((1 << lb3) - 1);
-        u >>= lb3;
-        const int z2 = u & (A.box[2] - 1);
-        u >>= A.lbox[2];
-        const int z1 = u & (A.box[1] - 1);
-        u >>= A.lbox[1];
-        const int x0 = o[0] + u, x1 = o[1] + z1, x2 = o[2] + z2, x3 = o[3] + 2 * p3 + shift;
-        if (co < A.cout && x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2] && x3 < A.L[3])
-          out_b[int64_t(co) * Vout + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + x3] =
-              activate(acc[mt][0][r] + bv, A.act);
-      }
-    return;
-  }
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    if constexpr (!Mma<T>::kStridedRows) {
-      // the 4 units of this lane are consecutive along the fastest box axis (box3 units >= 4 is
-      // guaranteed by the launcher): they share z0..z2 and form one 16-byte store
-      int x3u;
-      bool row_ok;
-      const int64_t base = unit_base(((wave * MT + mt) << 4) + (g << 2), x3u, row_ok);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int co = ((A.nt0 + nt) << 4) + (lane & 15);
-        if (!row_ok || co >= A.cout) continue;
-        const T bv = A.bias ? static_cast<const T *>(A.bias)[co] : T(0);
-        acc_t v = acc[mt][nt];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = activate(v[r] + bv, A.act);
-        T *dst = out_b + int64_t(co) * Vout + base;
-        if (x3u + 3 < L3u && ((Vout | base) & 3) == 0) {
-          *reinterpret_cast<acc_t *>(dst) = v;
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (x3u + r < L3u) dst[r] = v[r];
-        }
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int x3u;
-        bool row_ok;
-        const int64_t base = unit_base(((wave * MT + mt) << 4) + g + (r << 2), x3u, row_ok);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int co = ((A.nt0 + nt) << 4) + (lane & 15);
-          if (!row_ok || x3u >= L3u || co >= A.cout) continue;
-          const T bv = A.bias ? static_cast<const T *>(A.bias)[co] : T(0);
-          out_b[int64_t(co) * Vout + base] = activate(acc[mt][nt][r] + bv, A.act);
-        }
-      }
-    }
-  }
+  conv_epilogue<T, MT, NT, COMPACT, FUSE>(A, o, b, int64_t(b) * gridDim.x + blockIdx.x, acc, tile, red, wave, lane);
+  stamp(A, 6);
 }
 
 static int ilog2(int v) {
@@ -690,6 +448,10 @@ extern "C" int nf_conv_packed_steps(int cin, int ntaps) {
   return ((((cin * ntaps + 3) / 4) + 3) / 4) * 4;
 }
 extern "C" int nf_conv_ntiles(int cout) { return (cout + 15) >> 4; }
+
+static thread_local int g_last_path = 0;
+static thread_local int *g_dry_layout = nullptr;     // non-null: plan only (nf_conv_weight_layout)
+extern "C" int nf_conv_last_path(void) { return g_last_path; }
 
 struct FuseInfo {           // non-null => the coupling epilogue replaces the store
   int mode;                 // 1 forward, 2 inverse
@@ -750,7 +512,11 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
   static const int lds_cap_kb = getenv("NF_CONV_LDS_KB") ? atoi(getenv("NF_CONV_LDS_KB")) : 40;
   static const int box3_cap = getenv("NF_CONV_BOX3") ? atoi(getenv("NF_CONV_BOX3")) : 32;
   static const int mt_first = getenv("NF_CONV_MT") ? atoi(getenv("NF_CONV_MT")) : 4;
-  int MT = mt_first == 2 ? 2 : 4;
+  // layers the persistent kernel (nf_conv_pipe.hip) can take are planned with its MT = 2 boxes straight away
+  static const int pipe_off = getenv("NF_CONV_PIPE") ? (atoi(getenv("NF_CONV_PIPE")) == 0) : 0;
+  const bool pipe_candidate = sizeof(T) == 4 && !pipe_off && !A.packed && (cin & 3) == 0 && A.k[3] == 3 &&
+                              A.k[0] * A.k[1] * A.k[2] >= 2 && A.nt_total <= 3 && !A.dbg;
+  int MT = (mt_first == 2 || pipe_candidate) ? 2 : 4;
   int box[4];
   for (int attempt = 0; attempt < 2; ++attempt) {
     const int units = (kBlock / kWave) * MT * 16;
@@ -836,6 +602,24 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
     }
     *fz->blocks_out = nblocks;
   }
+  g_last_path = 0;
+  if (g_dry_layout) {                  // nf_conv_weight_layout: report which kernel (hence weight layout) this layer gets
+    int pr = 0;
+    if constexpr (sizeof(T) == 4) {
+      if (MT == 2) { A.nt0 = 0; pr = launch_conv_pipe(A, B, nblocks, fuse, stream, true); }
+    }
+    *g_dry_layout = pr == 1 ? 1 : 0;
+    return NF_OK;
+  }
+  if constexpr (sizeof(T) == 4) {
+    if (MT == 2) {     // persistent, staging-overlapped variant (nf_conv_pipe.hip) when the layer is eligible
+      A.nt0 = 0;
+      const int pr = launch_conv_pipe(A, B, nblocks, fuse, stream, false);
+      if (pr == -2) { set_error("nf_conv_fwd: batch x boxes >= 2^31 work items, split the batch"); return NF_EINVAL; }
+      if (pr < 0) { set_error("nf_conv_fwd: could not launch the pipelined kernel"); return NF_ELAUNCH; }
+      if (pr == 1) { g_last_path = 1; return check_launch("conv pipe kernel"); }
+    }
+  }
   static const int want_stamps = getenv("NF_CONV_STAMPS") ? atoi(getenv("NF_CONV_STAMPS")) : 0;
   unsigned long long *d_stamps = nullptr;
   if (want_stamps) {      // DIAGNOSTIC ONLY: allocates and synchronises, never enabled in product use
@@ -916,6 +700,24 @@ extern "C" int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, 
                            int compact, int active_parity, int dtype, void *stream) {
   return run_conv(in, wfrag, bias, out, B, lattice, ksize, cin, cout, act, compact, active_parity, dtype,
                   static_cast<hipStream_t>(stream), nullptr);
+}
+
+extern "C" int nf_conv_weight_layout(const int32_t *lattice, const int32_t *ksize, int cin, int cout, int compact,
+                                     int fused, int dtype) {
+  if (!lattice || !ksize) return -1;
+  int layout = 0;
+  int64_t blocks = 0;
+  FuseInfo fz{};
+  fz.mode = 1;
+  fz.partial = reinterpret_cast<double *>(uintptr_t(8));
+  fz.partial_bytes = ~size_t(0);
+  fz.blocks_out = &blocks;
+  void *dummy = reinterpret_cast<void *>(uintptr_t(8));   // never dereferenced: planning only
+  g_dry_layout = &layout;
+  const int rc = run_conv(dummy, dummy, nullptr, dummy, 1, lattice, ksize, cin, cout, 0, fused ? 1 : compact, 0, dtype,
+                          nullptr, fused ? &fz : nullptr);
+  g_dry_layout = nullptr;
+  return rc ? -1 : layout;
 }
 
 extern "C" int nf_conv_rqs_supported(int cout, int m) {

@@ -1,0 +1,331 @@
+// nf_conv_pipe.hip -- K5p: the fp32 circular convolution of nf_conv.hip as PERSISTENT workgroups
+// whose staging is overlapped with their own MFMAs.
+//
+// Why: in-kernel clock stamps on the one-box-per-workgroup kernel showed a
+// workgroup spending ~48 % of its life staging its input box (latency-bound 136-byte row loads)
+// and the other ~52 % issuing MFMAs, with too few co-resident workgroups to cover one phase with
+// another's.  Here a workgroup walks a list of (sample, box) items; the LDS holds TWO input
+// buffers of 4 channel planes; while the waves multiply out of one buffer they carry the loads of
+// the next (item, channel chunk) along: every iteration of the MFMA loop (two kernel rows, 2*K3*MT*NT
+// MFMAs) first issues a few global row loads into registers and, after its MFMAs, writes them into
+// the other buffer.  The load latency is hidden behind the matrix work of the same wave, the
+// row -> address arithmetic is scalar (rows are wave-uniform) and nothing is staged synchronously
+// except the very first chunk of a workgroup.
+//
+// Same math, operand layouts, weight fragments and epilogues as nf_conv.hip (reference:
+// src/nn/scalar/modules.py:120-145, src/nn/scalar/convNd.py:86-126); used by nf_conv_fwd /
+// nf_conv_rqs whenever the layer is eligible (fp32, cin % 4 == 0, kernel extent 3 along the
+// fastest axis, halo row <= 64 sites), otherwise the one-box kernel runs.
+#include <cstdio>
+#include <cstdlib>
+#include <hip/hip_runtime.h>
+#include "nf_conv_core.h"
+
+namespace nf {
+
+constexpr int kGPI = 2;        // row groups (x 4 channels) a wave loads per MFMA-loop iteration
+constexpr int kSlack = 64;     // dwords of slack at the end of every LDS plane: target of masked-off stores
+
+__device__ __forceinline__ int wrap1(int v, int L) {      // v in [-L, 2L)
+  return v < 0 ? v + L : (v >= L ? v - L : v);
+}
+
+template <int MT, int NT, int K3, bool COMPACT, int FUSE>
+__global__ __launch_bounds__(kBlock, 2) void conv_pipe_kernel(ConvArgs A) {
+  typedef float T;
+  typedef f32x4 acc_t;
+  extern __shared__ __align__(16) unsigned char smem_pipe[];
+  __shared__ double red[kBlock / kWave];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int nwaves = kBlock / kWave;
+  const int g = lane >> 4;
+  const int r0 = A.k[0] >> 1, r1 = A.k[1] >> 1, r2 = A.k[2] >> 1, r3 = A.k[3] >> 1;
+  const int h1 = A.hal[1], h2 = A.hal[2], h3 = A.hal[3];
+  const int R = A.hal[0] * h1 * h2;
+  const int bufsz = 4 * A.S;
+  T *buf = reinterpret_cast<T *>(smem_pipe);
+  auto rowz_of = [&](int t) {                               // halo row -> z0 | z1 << 8 | z2 << 16
+    const int z0 = t / (h1 * h2), rem = t - z0 * (h1 * h2);
+    const int z1 = rem / h2, z2 = rem - z1 * h2;
+    return z0 | (z1 << 8) | (z2 << 16);
+  };
+
+  // ---- the items of this workgroup.  Workgroups are dealt round-robin to the 8 XCDs; the remap
+  // gives each XCD a contiguous run of boxes at every step, so that neighbouring boxes (which share
+  // halo rows) meet in the same L2.
+  const int nb = gridDim.x;                                 // multiple of 8 (launcher)
+  const int vb = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
+  if (vb >= A.nitems) return;
+  const int n_my = int((A.nitems - vb + nb - 1) / nb);
+  const int nchunk = A.cin_pad >> 2;
+  const int gpw = (R + nwaves - 1) / nwaves;               // row groups per wave and phase
+  auto decode = [&](int it, int &b, int (&o)[4]) {          // nitems < 2^31 (launcher)
+    b = it / A.nboxes;
+    int bid = it - b * A.nboxes;
+#pragma unroll
+    for (int mu = 3; mu >= 0; --mu) {
+      o[mu] = (bid % A.nbox[mu]) * A.box[mu];
+      bid /= A.nbox[mu];
+    }
+  };
+
+  // ---- staging context of the NEXT phase.  Wave w copies halo rows w, w+4, ... ("groups" gi = 0..gpw-1, four
+  // channel planes each).  Lane l keeps, for group l, the row's offset in a channel plane of the input
+  // (`myoff`, recomputed when the next phase belongs to a new box) and in a plane of the LDS tile (`mydst`,
+  // the same for every box); issue() fetches both with v_readlane, so the copy loop carries no index math.
+  const T *__restrict__ nsrc = nullptr;
+  int nx3 = 0, myoff = 0;
+  T *nbuf = buf;
+  const int myrow = wave + nwaves * lane;                   // the halo row of group `lane`
+  const bool myvalid = lane < gpw && myrow < R;
+  const int mypz = myvalid ? rowz_of(myrow) : 0;
+  const int mydst = myvalid ? myrow * h3 : -1;
+  T sv[kGPI][4];
+  int sdst[kGPI];
+  auto issue = [&](int i) {
+#pragma unroll
+    for (int j = 0; j < kGPI; ++j) {
+      const int gi = i * kGPI + j;                          // < 64 (launcher: R <= 256)
+      const int off = __builtin_amdgcn_readlane(myoff, gi) + nx3;
+      const int drow = __builtin_amdgcn_readlane(mydst, gi);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sv[j][c] = nsrc[int64_t(c) * A.V + off];
+      sdst[j] = (drow >= 0 && lane < h3) ? drow + lane : A.S - kSlack + lane;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < kGPI; ++j)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) nbuf[c * A.S + sdst[j]] = sv[j][c];
+  };
+  auto set_next = [&](int b, const int (&o)[4], int q, T *dstbuf, bool new_box) {
+    nsrc = static_cast<const T *>(A.in) + (int64_t(b) * A.cin + 4 * q) * A.V;
+    nbuf = dstbuf;
+    if (new_box) {
+      nx3 = lane < h3 ? wrap1(o[3] + lane - r3, A.L[3]) : 0;
+      const int x0 = wrap1(o[0] + (mypz & 255) - r0, A.L[0]);
+      const int x1 = wrap1(o[1] + ((mypz >> 8) & 255) - r1, A.L[1]);
+      const int x2 = wrap1(o[2] + (mypz >> 16) - r2, A.L[2]);
+      myoff = ((x0 * A.L[1] + x1) * A.L[2] + x2) * A.L[3];  // lanes without a row: some valid offset, stored to the slack
+    }
+  };
+
+  // ---- per-lane A-fragment bases (as in nf_conv.hip); depend on the box only through the parity of its origin
+  const bool sh2 = !COMPACT && A.sh2;
+  const int lb3 = (COMPACT || sh2) ? A.lbox[3] - 1 : A.lbox[3];
+  int abase[MT];
+  auto set_abase = [&](const int (&o)[4]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      int u = ((wave * MT + mt) << 4) + (lane & 15);
+      const int p3 = u & ((1 << lb3) - 1);
+      u >>= lb3;
+      const int z2 = u & (A.box[2] - 1);
+      u >>= A.lbox[2];
+      const int z1 = u & (A.box[1] - 1);
+      u >>= A.lbox[1];
+      const int z0 = u;
+      int z3 = sh2 ? 2 * p3 : p3;
+      if (COMPACT) z3 = 2 * p3 + ((A.parity + o[0] + z0 + o[1] + z1 + o[2] + z2) & 1);
+      abase[mt] = ((z0 * h1 + z1) * h2 + z2) * h3 + z3 + g * A.S;
+    }
+  };
+
+  // ---- the MFMA loop of one phase: kernel rows in pairs (nf_conv.hip, mma_rows), the first `nst`
+  // iterations carrying the next phase's loads
+  const int nrows = A.k[0] * A.k[1] * A.k[2];
+  // weights: row-packed layout (include/normflow_hip.h, NF_WLAYOUT_ROWPACK): all K3*NT values a lane needs for
+  // one kernel row and channel quad are adjacent, so a row costs NV4 16-byte loads instead of K3*NT 4-byte ones
+  // (probe: tools/mfma_probe2.hip -- the per-fragment dword loads, not the MFMAs, capped the rate)
+  constexpr int NV4 = (K3 * NT + 3) / 4;
+  const f32x4 *__restrict__ wrow = static_cast<const f32x4 *>(A.wfrag) + lane * NV4;
+  acc_t acc[MT][NT];
+  auto phase_mma = [&](const T *tile, int kq0, int nst) {
+    T a0[K3][MT], a1[K3][MT];
+    f32x4 b0[NV4], b1[NV4];
+    int j1 = 0, j2 = 0, off = 0, row = 0;
+    auto next = [&]() {
+      if (row + 1 >= nrows) return;
+      ++row;
+      off += h3;
+      if (++j2 == A.k[2]) {
+        j2 = 0;
+        off += (h2 - A.k[2]) * h3;
+        if (++j1 == A.k[1]) {
+          j1 = 0;
+          off += (h1 - A.k[1]) * h2 * h3;
+        }
+      }
+    };
+    auto request = [&](T (&a)[K3][MT], f32x4 (&b)[NV4]) {
+      const f32x4 *__restrict__ wt = wrow + (int64_t(row) * A.kq_total + kq0) * (64 * NV4);
+#pragma unroll
+      for (int i = 0; i < NV4; ++i) b[i] = wt[i];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const T *pa = tile + abase[mt] + off;
+#pragma unroll
+        for (int j3 = 0; j3 < K3; ++j3) a[j3][mt] = pa[j3];
+      }
+    };
+    auto multiply = [&](const T (&a)[K3][MT], const f32x4 (&b)[NV4]) {
+#pragma unroll
+      for (int j3 = 0; j3 < K3; ++j3)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = Mma<T>::mma(a[j3][mt], b[(j3 * NT + nt) >> 2][(j3 * NT + nt) & 3], acc[mt][nt]);
+    };
+    request(a0, b0);
+    int r = 0, i = 0;
+    for (; i < nst && r + 1 < nrows; ++i, r += 2) {      // iterations that carry staging
+      next();
+      request(a1, b1);
+      issue(i);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      next();
+      request(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      commit();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    for (; r + 1 < nrows; r += 2) {
+      next();
+      request(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      next();
+      request(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (r < nrows) multiply(a0, b0);
+    for (; i < nst; ++i) {                                // groups the MFMA loop had no iterations for
+      issue(i);
+      commit();
+    }
+  };
+
+  // ---- prologue: the first chunk of the first item is staged synchronously
+  const int nst_full = (gpw + kGPI - 1) / kGPI;
+  int cb, co[4];
+  decode(vb, cb, co);
+  set_next(cb, co, 0, buf, true);
+  for (int i = 0; i < nst_full; ++i) {
+    issue(i);
+    commit();
+  }
+  __syncthreads();
+
+  const int P = n_my * nchunk;
+  int q = 0, m = 0;                                       // chunk within the item, item counter
+  for (int p = 0; p < P; ++p) {
+    T *cur = buf + (p & 1) * bufsz;
+    if (q == 0) {
+      set_abase(co);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{0.f, 0.f, 0.f, 0.f};
+    }
+    // what the next phase needs
+    int nb_ = cb, no_[4] = {co[0], co[1], co[2], co[3]};
+    const bool last_chunk = q + 1 == nchunk;
+    if (last_chunk && p + 1 < P) decode(vb + (m + 1) * nb, nb_, no_);
+    set_next(nb_, no_, last_chunk ? 0 : q + 1, buf + ((p + 1) & 1) * bufsz, last_chunk);
+    phase_mma(cur, q, p + 1 < P ? nst_full : 0);
+    __syncthreads();      // everyone is done reading `cur`; the next phase's planes are complete
+    if (last_chunk) {
+      conv_epilogue<T, MT, NT, COMPACT, FUSE>(A, co, cb, int64_t(vb) + int64_t(m) * nb, acc, cur, red, wave, lane);
+      if constexpr (FUSE > 0) __syncthreads();            // `cur` served as scratch; it is staged into next
+      cb = nb_;
+#pragma unroll
+      for (int mu = 0; mu < 4; ++mu) co[mu] = no_[mu];
+      q = 0;
+      ++m;
+    } else {
+      ++q;
+    }
+  }
+}
+
+template <int MT, int NT, int K3, bool COMPACT, int FUSE>
+static int launch_pipe_one(const ConvArgs &A, size_t lds, hipStream_t stream) {
+  const void *fn = reinterpret_cast<const void *>(&conv_pipe_kernel<MT, NT, K3, COMPACT, FUSE>);
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    ncu = prop.multiProcessorCount;
+  }
+  if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) return -1;
+  int blocks_per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, kBlock, lds) != hipSuccess || blocks_per_cu < 1)
+    blocks_per_cu = 1;
+  int64_t grid = int64_t(blocks_per_cu) * ncu;
+  if (grid > A.nitems) grid = A.nitems;
+  grid = (grid + 7) & ~int64_t(7);
+  hipLaunchKernelGGL((conv_pipe_kernel<MT, NT, K3, COMPACT, FUSE>), dim3(unsigned(grid)), dim3(kBlock), lds, stream, A);
+  return 1;
+}
+
+// Returns 1 when the layer was launched here, 0 when it is not eligible (the caller falls back to
+// the one-box kernel), < 0 on error.  `A0` is the fully planned argument block of nf_conv.hip
+// (MT = 2 boxes); only the plane stride is re-planned (slack for masked stores).
+int launch_conv_pipe(const ConvArgs &A0, int64_t B, int64_t nboxes, int fuse, hipStream_t stream, bool dry) {
+  static const int off = getenv("NF_CONV_PIPE") ? (atoi(getenv("NF_CONV_PIPE")) == 0) : 0;
+  if (off) return 0;
+  ConvArgs A = A0;
+  if (A.packed || (A.cin & 3) || A.k[3] != 3 || A.hal[3] > 64 || A.dbg || A.stamps) return 0;
+  if (A.nt_total - A.nt0 > 3 || A.nt0 != 0) return 0;
+  const int nrows = A.k[0] * A.k[1] * A.k[2];
+  if (nrows < 2) return 0;
+  for (int mu = 0; mu < 4; ++mu) {
+    const int r = A.k[mu] >> 1;
+    if (r > A.L[mu] || A.nbox[mu] * A.box[mu] + r - 1 >= 2 * A.L[mu]) return 0;    // wrap1's range
+    if (A.hal[mu] > 255) return 0;
+  }
+  int64_t halvol = 1, rows = 1;
+  for (int mu = 0; mu < 4; ++mu) halvol *= A.hal[mu];
+  for (int mu = 0; mu < 3; ++mu) rows *= A.hal[mu];
+  int S = int(halvol) + kSlack;
+  if (A.compact || A.sh2) S |= 1; else S = ((S + 15) & ~31) + 16;
+  A.S = S;
+  A.cchunk = 4;
+  A.nitems = B * nboxes;
+  if (!dry && A.nitems >= (int64_t(1) << 31) - 4096) return -2;
+  A.nboxes = int(nboxes);
+  const size_t lds = size_t(2) * 4 * S * sizeof(float);
+  if (rows > 256) return 0;                                 // one lane per row group of a wave (v_readlane)
+  if (lds > 160 * 1024) return 0;
+  if (fuse && size_t(48) * ((kBlock / kWave) * 2 * 16 + 4) * sizeof(float) > size_t(4) * S * sizeof(float)) return 0;
+  if (dry) return 1;
+  const int n = A.nt_total;
+  if (fuse) {
+    if (n == 3) return fuse == 1 ? launch_pipe_one<2, 3, 3, true, 1>(A, lds, stream) : launch_pipe_one<2, 3, 3, true, 2>(A, lds, stream);
+    if (n == 2) return fuse == 1 ? launch_pipe_one<2, 2, 3, true, 1>(A, lds, stream) : launch_pipe_one<2, 2, 3, true, 2>(A, lds, stream);
+    return fuse == 1 ? launch_pipe_one<2, 1, 3, true, 1>(A, lds, stream) : launch_pipe_one<2, 1, 3, true, 2>(A, lds, stream);
+  }
+  if (A.sh2) return launch_pipe_one<2, 1, 4, false, 0>(A, lds, stream);
+  if (A.compact) {
+    if (n == 3) return launch_pipe_one<2, 3, 3, true, 0>(A, lds, stream);
+    if (n == 2) return launch_pipe_one<2, 2, 3, true, 0>(A, lds, stream);
+    return launch_pipe_one<2, 1, 3, true, 0>(A, lds, stream);
+  }
+  if (n == 3) return launch_pipe_one<2, 3, 3, false, 0>(A, lds, stream);
+  if (n == 2) return launch_pipe_one<2, 2, 3, false, 0>(A, lds, stream);
+  return launch_pipe_one<2, 1, 3, false, 0>(A, lds, stream);
+}
+
+}  // namespace nf

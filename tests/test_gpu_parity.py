@@ -579,6 +579,76 @@ def test_fused_conv_spline_epilogue_matches_unfused(m, shape):
     assert rel(y1, y2) <= 2e-6 and rel(l1, l2) <= 2e-6
 
 
+PIPE_CASES = [
+    # (lattice, cin, cout, B): eligible for the persistent staging-overlapped kernel (fp32, cin % 4 == 0, k = 3);
+    # B chosen so that workgroups walk several (sample, box) items and both LDS buffers change hands
+    ((8, 8, 8, 16), 8, 46, 40), ((8, 8, 8, 16), 8, 8, 40), ((6, 4, 6, 12), 4, 20, 150), ((8, 8, 8, 8), 12, 8, 70),
+    ((8, 16, 32), 8, 30, 24), ((16, 16), 8, 46, 300),
+]
+
+
+@pytest.mark.parametrize("lattice,cin,cout,B", PIPE_CASES)
+def test_conv_pipelined_kernel_vs_oracle(lattice, cin, cout, B):
+    """nf_conv_pipe.hip (persistent workgroups, double-buffered LDS, staging carried by the MFMA loop)
+    against the fp64 definition, full and pair-compact outputs, many items per workgroup; the test
+    also asserts that this kernel is the one that ran."""
+    d = len(lattice)
+    g = torch.Generator(device='cpu').manual_seed(7 + cin + cout)
+    x = torch.randn((B, cin) + lattice, generator=g, dtype=torch.float64, device='cpu')
+    w = 0.3 * torch.randn((cout, cin) + (3,) * d, generator=g, dtype=torch.float64, device='cpu')
+    b = torch.randn(cout, generator=g, dtype=torch.float64, device='cpu')
+    ref = torch.tanh(O.circular_conv_fast(x, w, b))
+    xd, wd, bd = (t.to(DEV, torch.float32) for t in (x, w, b))
+    tol = 1e-6 + 2e-7 * 0.3 * cin * 3 ** d
+    out = _hip.conv_layer(xd, wd, bd, _hip.ACT_CODES['tanh'])
+    assert _hip.load().nf_conv_last_path() == 1
+    assert rel(out, ref) <= tol
+    for parity in (0, 1):
+        act_mask = (O.even_odd_mask(lattice, parity=0) == (1 - parity)).reshape(-1).to(DEV)
+        comp = _hip.conv_layer(xd, wd, bd, _hip.ACT_CODES['tanh'], compact=True, parity=parity)
+        assert _hip.load().nf_conv_last_path() == 1
+        want = compact(T(ref.reshape(B, cout, -1).numpy(), torch.float64), act_mask.to(torch.uint8))
+        assert comp.shape == want.shape and rel(comp, want) <= tol
+
+
+def test_fused_epilogue_on_pipelined_kernel_multi_item():
+    """nf_conv_rqs through the persistent kernel with several items per workgroup (the epilogue borrows
+    the LDS buffer that the next phase is about to be staged into): vs conv + coupling kernels run
+    separately and vs the fp64 oracle; forward and inverse."""
+    torch.manual_seed(11)
+    shape, m, B = (8, 8, 8, 16), 16, 48
+    C = 3 * m - 2
+    net = ConvAct(1, C, 3, conv_dim=4, hidden_sizes=[8, 8], acts=['tanh', 'tanh', None]).to(DEV, torch.float32)
+    with torch.no_grad():
+        for p in list(net.parameters())[-2:]:
+            p.mul_(0.3)
+    mask = EvenOddMask(shape=shape)
+    lim = dict(xlim=(-4.0, 4.0), ylim=(-4.0, 4.0), extrap={'left': 'linear', 'right': 'linear'})
+    cpl = RQSplineCoupling_([net, net], mask=mask, **lim).to(DEV)
+    x = 1.5 * torch.randn((B,) + shape, device=DEV, dtype=torch.float32)
+    for parity in (0, 1):
+        xa, xf = mask.purify(x, parity), mask.purify(x, 1 - parity)
+        l0 = torch.randn(B, device=DEV, dtype=torch.float32)
+        with torch.no_grad():
+            yf, lf = cpl._fused_atom(False, xa, xf, parity, net, l0)
+            assert _hip.load().nf_conv_last_path() == 1
+            params, lay = cpl._params(net, xf, parity)
+            opts = _hip.make_rqs_opts(m, lim["xlim"], lim["ylim"], lim["extrap"], lay)
+            act = mask.activity(parity).reshape(-1).to(DEV)
+            yu, lu = _hip.RQSCouplingFn.apply(xa.reshape(B, -1), params, l0, act, opts, False)
+            assert rel(yf.reshape(B, -1), yu) <= 2e-6 and rel(lf, lu) <= 2e-6
+            xb, lb = cpl._fused_atom(True, yf, xf, parity, net, lf)
+            assert rel(xb, xa) <= 5e-4 and rel(lb, l0) <= 5e-4
+        if parity == 0:
+            convs = [mod for mod in net if hasattr(mod, 'weight')]
+            layers = [(c.weight.detach().double().cpu(), c.bias.detach().double().cpu()) for c in convs]
+            nb = 6                                  # the oracle on a few samples is enough here
+            out = O.conv_act(xf[:nb].double().cpu().unsqueeze(1), layers, ['tanh', 'tanh', None])
+            yo, lo = O.rqs_coupling_atom(xa[:nb].double().cpu(), out, O.channel_mask(shape, parity),
+                                         log0=l0[:nb].double().cpu(), **lim)
+            assert rel(yf[:nb], yo) <= 1e-5 and rel(lf[:nb], lo) <= 1e-5
+
+
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_endpoint_kernels_against_goldens(golden, dtype):
     """phi^4 action and normal-prior log-density kernels vs the reference's values (callers.npz),
