@@ -244,7 +244,7 @@ def main():
                    "in_timed_pipeline": not fused}
         if fused:
             ft = time_fused_last_layer(cpl, lattice, a.knots, dev, max(2, a.kernel_reps // 3), a.batch)
-            roof = {"kernel": "nf::conv_kernel<2,3,compact,fused-rqs-fwd> (last conv layer 8->46 at the active sites "
+            roof = {"kernel": "nf::conv_pipe_kernel<2,3,3,compact,fused-rqs-fwd,wide,unrolled> (last conv layer 8->46 at the active sites "
                               "+ RQ-spline coupling epilogue; dominant kernel of the timed region)",
                     "bound": "mfma", "achieved": ft["tflops"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ft["tflops"] / MFMA_F32_PEAK_TFLOPS, "traffic": None,

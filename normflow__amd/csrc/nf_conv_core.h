@@ -53,6 +53,7 @@ struct ConvArgs {
   int dbg;              // profiling ablation (NF_CONV_DBG): bit0 skip staging, bit1 skip the MFMA loop
   int64_t nitems;       // nf_conv_pipe.hip: (sample, box) items in the launch, boxes per sample
   int nboxes;
+  int wide_no, wide_llpr;   // nf_conv_pipe.hip wide staging: row blocks per wave (0 = narrow), log2(lanes per row)
 };
 
 __device__ __forceinline__ float activate(float v, int act) {

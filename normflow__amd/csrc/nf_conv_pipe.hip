@@ -30,8 +30,9 @@ __device__ __forceinline__ int wrap1(int v, int L) {      // v in [-L, 2L)
   return v < 0 ? v + L : (v >= L ? v - L : v);
 }
 
-template <int MT, int NT, int K3, bool COMPACT, int FUSE>
+template <int MT, int NT, int K3, bool COMPACT, int FUSE, bool WIDE, bool HOT>
 __global__ __launch_bounds__(kBlock, 2) void conv_pipe_kernel(ConvArgs A) {
+  static_assert(!HOT || WIDE, "the unrolled schedule is written for wide staging");
   typedef float T;
   typedef f32x4 acc_t;
   extern __shared__ __align__(16) unsigned char smem_pipe[];
@@ -70,45 +71,100 @@ __global__ __launch_bounds__(kBlock, 2) void conv_pipe_kernel(ConvArgs A) {
     }
   };
 
-  // ---- staging context of the NEXT phase.  Wave w copies halo rows w, w+4, ... ("groups" gi = 0..gpw-1, four
-  // channel planes each).  Lane l keeps, for group l, the row's offset in a channel plane of the input
-  // (`myoff`, recomputed when the next phase belongs to a new box) and in a plane of the LDS tile (`mydst`,
-  // the same for every box); issue() fetches both with v_readlane, so the copy loop carries no index math.
+  // ---- staging context of the NEXT phase: the wave's share of the halo rows x 4 channel planes, cut into
+  // "groups" that issue() loads into registers and commit() writes to the other LDS buffer.
+  //  * WIDE (the box spans whole lattice rows, L3 in {8,16,32,64}): a group = RPI = 256/L3 rows of ONE channel; lane
+  //    (rr, k) loads the 16 bytes k of row rr (one global_load_dwordx4 covers RPI complete, aligned rows) and stores
+  //    them as two ds_write2_b32; the two halo sites of a row are its own end elements (periodic wrap), written by
+  //    the row's edge lanes.  4 instructions move what takes 2*RPI in the narrow scheme -- the vector-memory
+  //    instruction count, not the bytes, is what the MFMA loop feels (tools/mfma_probe2.hip).
+  //  * narrow (any box): a group = one row x 4 channels, one dword per lane; lane l keeps the source / LDS row
+  //    offsets of group l and issue() fetches them with v_readlane.
+  // Row offsets in the input are recomputed only when the next phase belongs to a new box.
   const T *__restrict__ nsrc = nullptr;
-  int nx3 = 0, myoff = 0;
   T *nbuf = buf;
-  const int myrow = wave + nwaves * lane;                   // the halo row of group `lane`
+  constexpr int kG = WIDE ? 1 : kGPI;                       // groups per MFMA-loop iteration
+  // narrow state
+  int nx3 = 0, myoff = 0;
+  const int myrow = wave + nwaves * lane;
   const bool myvalid = lane < gpw && myrow < R;
   const int mypz = myvalid ? rowz_of(myrow) : 0;
   const int mydst = myvalid ? myrow * h3 : -1;
   T sv[kGPI][4];
   int sdst[kGPI];
+  // wide state
+  const int llpr = A.wide_llpr, lpr = 1 << llpr, rpi = 64 >> llpr;
+  const int wk = lane & (lpr - 1);
+  int wpz[4], wdst[4], whalo[4], woff[4] = {0, 0, 0, 0};
+  if constexpr (WIDE) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      int row = rpi * (nwaves * o + wave) + (lane >> llpr);
+      if (row >= R) row = (lane >> llpr) < R ? (lane >> llpr) : 0;     // spare lanes repeat an early row (same data, same place)
+      wpz[o] = rowz_of(row);
+      wdst[o] = row * h3 + 1 + 4 * wk;
+      whalo[o] = wk == 0 ? row * h3 + h3 - 1 : (wk == lpr - 1 ? row * h3 : A.S - kSlack + lane);
+    }
+  }
+  f32x4 svw = {0.f, 0.f, 0.f, 0.f};
+  int sc = 0, so = 0;
+  auto pick = [&](const int (&arr)[4], int o) {
+    int v = arr[0];
+    if (o == 1) v = arr[1];
+    if (o == 2) v = arr[2];
+    if (o == 3) v = arr[3];
+    return v;
+  };
+  const int ngroups = WIDE ? 4 * A.wide_no : gpw;
   auto issue = [&](int i) {
+    if constexpr (WIDE) {
+      so = i >> 2;
+      sc = i & 3;
+      svw = *reinterpret_cast<const f32x4 *>(nsrc + int64_t(sc) * A.V + pick(woff, so));
+    } else {
 #pragma unroll
-    for (int j = 0; j < kGPI; ++j) {
-      const int gi = i * kGPI + j;                          // < 64 (launcher: R <= 256)
-      const int off = __builtin_amdgcn_readlane(myoff, gi) + nx3;
-      const int drow = __builtin_amdgcn_readlane(mydst, gi);
+      for (int j = 0; j < kGPI; ++j) {
+        const int gi = i * kGPI + j;                          // < 64 (launcher: R <= 256)
+        const int off = __builtin_amdgcn_readlane(myoff, gi) + nx3;
+        const int drow = __builtin_amdgcn_readlane(mydst, gi);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) sv[j][c] = nsrc[int64_t(c) * A.V + off];
-      sdst[j] = (drow >= 0 && lane < h3) ? drow + lane : A.S - kSlack + lane;
+        for (int c = 0; c < 4; ++c) sv[j][c] = nsrc[int64_t(c) * A.V + off];
+        sdst[j] = (drow >= 0 && lane < h3) ? drow + lane : A.S - kSlack + lane;
+      }
     }
   };
   auto commit = [&]() {
+    if constexpr (WIDE) {
+      T *pl = nbuf + sc * A.S;
+      const int d = pick(wdst, so);
+      pl[d] = svw[0]; pl[d + 1] = svw[1]; pl[d + 2] = svw[2]; pl[d + 3] = svw[3];
+      pl[pick(whalo, so)] = wk == 0 ? svw[0] : svw[3];
+    } else {
 #pragma unroll
-    for (int j = 0; j < kGPI; ++j)
+      for (int j = 0; j < kGPI; ++j)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) nbuf[c * A.S + sdst[j]] = sv[j][c];
+        for (int c = 0; c < 4; ++c) nbuf[c * A.S + sdst[j]] = sv[j][c];
+    }
   };
   auto set_next = [&](int b, const int (&o)[4], int q, T *dstbuf, bool new_box) {
     nsrc = static_cast<const T *>(A.in) + (int64_t(b) * A.cin + 4 * q) * A.V;
     nbuf = dstbuf;
     if (new_box) {
-      nx3 = lane < h3 ? wrap1(o[3] + lane - r3, A.L[3]) : 0;
-      const int x0 = wrap1(o[0] + (mypz & 255) - r0, A.L[0]);
-      const int x1 = wrap1(o[1] + ((mypz >> 8) & 255) - r1, A.L[1]);
-      const int x2 = wrap1(o[2] + (mypz >> 16) - r2, A.L[2]);
-      myoff = ((x0 * A.L[1] + x1) * A.L[2] + x2) * A.L[3];  // lanes without a row: some valid offset, stored to the slack
+      if constexpr (WIDE) {
+#pragma unroll
+        for (int oo = 0; oo < 4; ++oo) {
+          const int x0 = wrap1(o[0] + (wpz[oo] & 255) - r0, A.L[0]);
+          const int x1 = wrap1(o[1] + ((wpz[oo] >> 8) & 255) - r1, A.L[1]);
+          const int x2 = wrap1(o[2] + (wpz[oo] >> 16) - r2, A.L[2]);
+          woff[oo] = ((x0 * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + 4 * wk;
+        }
+      } else {
+        nx3 = lane < h3 ? wrap1(o[3] + lane - r3, A.L[3]) : 0;
+        const int x0 = wrap1(o[0] + (mypz & 255) - r0, A.L[0]);
+        const int x1 = wrap1(o[1] + ((mypz >> 8) & 255) - r1, A.L[1]);
+        const int x2 = wrap1(o[2] + (mypz >> 16) - r2, A.L[2]);
+        myoff = ((x0 * A.L[1] + x1) * A.L[2] + x2) * A.L[3];  // lanes without a row: some valid offset, stored to the slack
+      }
     }
   };
 
@@ -215,8 +271,66 @@ __global__ __launch_bounds__(kBlock, 2) void conv_pipe_kernel(ConvArgs A) {
     }
   };
 
+  // ---- HOT: the 3x3x3(x3) kernel with 8 staging groups per wave and phase (the 4-d ConvAct layers on a box of
+  // 2x2x2 full rows).  The 13 row pairs are unrolled, so the row walk is constant-folded and -- the point --
+  // staging group g is issued in pair g and committed in pair g + kLag: the load has kLag pairs (~3.5k cycles of
+  // MFMA work) to land, where the rolled loop commits in the pair it issues in and stalls on every L2/HBM miss
+  // (measured: 12-18 % of the kernel).  The block's last phase re-stages its own chunk into the idle buffer so
+  // that the schedule has no conditionals.
+  constexpr int kLag = 3;
+  auto phase_mma_hot = [&](const T *tile, int kq0) {
+    T a0[K3][MT], a1[K3][MT];
+    f32x4 b0[NV4], b1[NV4];
+    f32x4 sh[8];
+    auto rowoff = [&](int row) { return (((row / 9) * h1 + (row / 3) % 3) * h2 + row % 3) * h3; };
+    auto request = [&](T (&a)[K3][MT], f32x4 (&b)[NV4], int row) {
+      const f32x4 *__restrict__ wt = wrow + (int64_t(row) * A.kq_total + kq0) * (64 * NV4);
+#pragma unroll
+      for (int i = 0; i < NV4; ++i) b[i] = wt[i];
+      const int off = rowoff(row);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const T *pa = tile + abase[mt] + off;
+#pragma unroll
+        for (int j3 = 0; j3 < K3; ++j3) a[j3][mt] = pa[j3];
+      }
+    };
+    auto multiply = [&](const T (&a)[K3][MT], const f32x4 (&b)[NV4]) {
+#pragma unroll
+      for (int j3 = 0; j3 < K3; ++j3)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = Mma<T>::mma(a[j3][mt], b[(j3 * NT + nt) >> 2][(j3 * NT + nt) & 3], acc[mt][nt]);
+    };
+    request(a0, b0, 0);
+#pragma unroll
+    for (int t = 0; t < 13; ++t) {
+      request(a1, b1, 2 * t + 1);
+      if (t < 8) sh[t] = *reinterpret_cast<const f32x4 *>(nsrc + int64_t(t & 3) * A.V + woff[t >> 2]);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      request(a0, b0, 2 * t + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t >= kLag && t - kLag < 8) {
+        constexpr int dummy = 0; (void)dummy;
+        const int g8 = t - kLag;
+        T *pl = nbuf + (g8 & 3) * A.S;
+        const int d = wdst[g8 >> 2];
+        pl[d] = sh[g8][0]; pl[d + 1] = sh[g8][1]; pl[d + 2] = sh[g8][2]; pl[d + 3] = sh[g8][3];
+        pl[whalo[g8 >> 2]] = wk == 0 ? sh[g8][0] : sh[g8][3];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    multiply(a0, b0);
+  };
+
   // ---- prologue: the first chunk of the first item is staged synchronously
-  const int nst_full = (gpw + kGPI - 1) / kGPI;
+  const int nst_full = (ngroups + kG - 1) / kG;
   int cb, co[4];
   decode(vb, cb, co);
   set_next(cb, co, 0, buf, true);
@@ -242,9 +356,11 @@ __global__ __launch_bounds__(kBlock, 2) void conv_pipe_kernel(ConvArgs A) {
     const bool last_chunk = q + 1 == nchunk;
     if (last_chunk && p + 1 < P) decode(vb + (m + 1) * nb, nb_, no_);
     set_next(nb_, no_, last_chunk ? 0 : q + 1, buf + ((p + 1) & 1) * bufsz, last_chunk);
-    phase_mma(cur, q, p + 1 < P ? nst_full : 0);
+    if constexpr (HOT) phase_mma_hot(cur, q);
+    else phase_mma(cur, q, (p + 1 < P && !(A.dbg & 16)) ? nst_full : 0);     // dbg 16: timing ablation, no staging
     __syncthreads();      // everyone is done reading `cur`; the next phase's planes are complete
     if (last_chunk) {
+      if (!(A.dbg & 32))                                    // dbg 32: timing ablation, no epilogue
       conv_epilogue<T, MT, NT, COMPACT, FUSE>(A, co, cb, int64_t(vb) + int64_t(m) * nb, acc, cur, red, wave, lane);
       if constexpr (FUSE > 0) __syncthreads();            // `cur` served as scratch; it is staged into next
       cb = nb_;
@@ -258,9 +374,9 @@ __global__ __launch_bounds__(kBlock, 2) void conv_pipe_kernel(ConvArgs A) {
   }
 }
 
-template <int MT, int NT, int K3, bool COMPACT, int FUSE>
-static int launch_pipe_one(const ConvArgs &A, size_t lds, hipStream_t stream) {
-  const void *fn = reinterpret_cast<const void *>(&conv_pipe_kernel<MT, NT, K3, COMPACT, FUSE>);
+template <int MT, int NT, int K3, bool COMPACT, int FUSE, bool WIDE, bool HOT>
+static int launch_pipe_w(const ConvArgs &A, size_t lds, hipStream_t stream) {
+  const void *fn = reinterpret_cast<const void *>(&conv_pipe_kernel<MT, NT, K3, COMPACT, FUSE, WIDE, HOT>);
   static int ncu = 0;
   if (!ncu) {
     int dev = 0;
@@ -276,8 +392,17 @@ static int launch_pipe_one(const ConvArgs &A, size_t lds, hipStream_t stream) {
   int64_t grid = int64_t(blocks_per_cu) * ncu;
   if (grid > A.nitems) grid = A.nitems;
   grid = (grid + 7) & ~int64_t(7);
-  hipLaunchKernelGGL((conv_pipe_kernel<MT, NT, K3, COMPACT, FUSE>), dim3(unsigned(grid)), dim3(kBlock), lds, stream, A);
+  hipLaunchKernelGGL((conv_pipe_kernel<MT, NT, K3, COMPACT, FUSE, WIDE, HOT>), dim3(unsigned(grid)), dim3(kBlock), lds, stream, A);
   return 1;
+}
+
+template <int MT, int NT, int K3, bool COMPACT, int FUSE>
+static int launch_pipe_one(const ConvArgs &A, size_t lds, hipStream_t stream) {
+  static const int hot_off = getenv("NF_CONV_PIPE_ROLLED") ? 1 : 0;      // A/B knob
+  const bool hot = !hot_off && A.wide_no == 2 && A.k[0] == 3 && A.k[1] == 3 && A.k[2] == 3 && !(A.dbg & 16);
+  if (hot) return launch_pipe_w<MT, NT, K3, COMPACT, FUSE, true, true>(A, lds, stream);
+  return A.wide_no ? launch_pipe_w<MT, NT, K3, COMPACT, FUSE, true, false>(A, lds, stream)
+                   : launch_pipe_w<MT, NT, K3, COMPACT, FUSE, false, false>(A, lds, stream);
 }
 
 // Returns 1 when the layer was launched here, 0 when it is not eligible (the caller falls back to
@@ -287,7 +412,22 @@ int launch_conv_pipe(const ConvArgs &A0, int64_t B, int64_t nboxes, int fuse, hi
   static const int off = getenv("NF_CONV_PIPE") ? (atoi(getenv("NF_CONV_PIPE")) == 0) : 0;
   if (off) return 0;
   ConvArgs A = A0;
-  if (A.packed || (A.cin & 3) || A.k[3] != 3 || A.hal[3] > 64 || A.dbg || A.stamps) return 0;
+  if (A.packed || (A.cin & 3) || A.k[3] != 3 || (A.dbg & 15) || A.stamps) return 0;
+  A.wide_no = 0; A.wide_llpr = 0;
+  {
+    static const int wide_off = getenv("NF_CONV_PIPE_NARROW") ? 1 : 0;     // A/B knob
+    const int L3 = A.L[3];
+    int64_t rows3 = 1;
+    for (int mu = 0; mu < 3; ++mu) rows3 *= A.hal[mu];
+    if (!wide_off && A.nbox[3] == 1 && A.box[3] == L3 && (L3 == 8 || L3 == 16 || L3 == 32 || L3 == 64)) {
+      int llpr = 1;
+      while ((4 << llpr) < L3) ++llpr;
+      const int rpi = 64 >> llpr;
+      const int64_t no = (rows3 + rpi * 4 - 1) / (rpi * 4);
+      if (no <= 4) { A.wide_no = int(no); A.wide_llpr = llpr; }
+    }
+  }
+  if (!A.wide_no && A.hal[3] > 64) return 0;
   if (A.nt_total - A.nt0 > 3 || A.nt0 != 0) return 0;
   const int nrows = A.k[0] * A.k[1] * A.k[2];
   if (nrows < 2) return 0;
