@@ -208,7 +208,8 @@ int nf_conv_weight_layout(const int32_t *lattice, const int32_t *ksize, int cin,
                           int fused, int dtype);
 /* Which kernel the calling thread's last nf_conv_fwd / nf_conv_rqs launched: 0 = one box per workgroup
  * (nf_conv.hip), 1 = persistent workgroups with staging overlapped with the MFMAs (nf_conv_pipe.hip;
- * fp32, cin % 4 == 0, kernel extent 3 on the fastest axis).  Same results either way; for tests and benches. */
+ * fp32, cin % 4 == 0, kernel extent 3 on the fastest axis), 2 = the single-input-channel kernel of the first
+ * ConvAct layer (nf_conv_pipe.hip, conv_c1_kernel).  Same results either way; for tests and benches. */
 int nf_conv_last_path(void);
 
 /* ---- K5+K2 fused: last conv layer of the parameter net + RQ-spline coupling ---------------

@@ -582,6 +582,10 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
     const size_t stage = size_t(48) * ((kBlock / kWave) * MT * 16 + 4) * sizeof(float);
     if (lds < stage) lds = stage;
   }
+  if (A.sh2) {       // the two-site epilogue transposes the box through LDS: 8 channels x (sites of the box + 8)
+    const size_t stage = size_t(8) * (2 * (kBlock / kWave) * MT * 16 + 8) * sizeof(T);
+    if (lds < stage) lds = stage;
+  }
   {
     static const int pad_kb = getenv("NF_CONV_LDS_PAD_KB") ? atoi(getenv("NF_CONV_LDS_PAD_KB")) : 0;   // occupancy experiments
     lds += size_t(pad_kb) * 1024;
@@ -610,6 +614,14 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
     }
     *g_dry_layout = pr == 1 ? 1 : 0;
     return NF_OK;
+  }
+  if constexpr (sizeof(T) == 4) {
+    if (cin == 1 && A.sh2 && !fz) {     // first ConvAct layer: data-movement kernel (nf_conv_pipe.hip, K5c)
+      const int pr = launch_conv_c1(A, MT, B, nblocks, stream);
+      if (pr == -2) { set_error("nf_conv_fwd: batch x boxes >= 2^31 work items, split the batch"); return NF_EINVAL; }
+      if (pr < 0) { set_error("nf_conv_fwd: could not launch the single-channel kernel"); return NF_ELAUNCH; }
+      if (pr == 1) { g_last_path = 2; return check_launch("conv c1 kernel"); }
+    }
   }
   if constexpr (sizeof(T) == 4) {
     if (MT == 2) {     // persistent, staging-overlapped variant (nf_conv_pipe.hip) when the layer is eligible

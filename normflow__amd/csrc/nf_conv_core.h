@@ -56,9 +56,16 @@ struct ConvArgs {
   int wide_no, wide_llpr;   // nf_conv_pipe.hip wide staging: row blocks per wave (0 = narrow), log2(lanes per row)
 };
 
+// tanh on the hardware exp/rcp: (1 - t) / (1 + t), t = exp(-2|v|); absolute error ~1e-7 (the fp32 rounding of an
+// O(1) activation), ~8 instructions where ocml's tanhf takes ~40 -- it was most of the 8->8 layer's epilogue.
+__device__ __forceinline__ float fast_tanh(float v) {
+  const float t = __expf(-2.f * fabsf(v));
+  return copysignf((1.f - t) * __frcp_rn(1.f + t), v);
+}
+
 __device__ __forceinline__ float activate(float v, int act) {
   switch (act) {
-    case kActTanh: return tanhf(v);
+    case kActTanh: return fast_tanh(v);
     case kActRelu: return v > 0.f ? v : 0.f;
     case kActLeakyRelu: return v > 0.f ? v : 0.01f * v;
     case kActSoftplus: return v > 20.f ? v : log1pf(expf(v));
@@ -203,6 +210,42 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, const int (&o)[
     // columns 0-7: channel co at site 2p; columns 8-15: channel co at site 2p + 1
     const int co = lane & 7, shift = (lane >> 3) & 1;
     const T bv = (A.bias && co < A.cout) ? static_cast<const T *>(A.bias)[co] : T(0);
+    if constexpr (!Mma<T>::kStridedRows) {
+      if ((A.L[3] & 3) == 0) {
+        // Through LDS, so that the box leaves as whole 16-byte pieces of lattice rows (8 complete rows per store
+        // instruction) instead of 8-byte pairs scattered over 32 rows: ot[co][row of the box][x3].
+        constexpr int UNITS = (kBlock / kWave) * MT * 16;
+        const int b3 = 2 << lb3, lrows_units = lb3;              // sites per box row; units per row = 1 << lb3
+        const int rows = UNITS >> lrows_units;
+        const int CS = rows * b3 + 8;                            // channel stride: +8 floats spreads the channels over banks
+        __syncthreads();                                         // every wave is done with the input tile
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int u = ((wave * MT + mt) << 4) + (g << 2) + r;
+            const int p3 = u & ((1 << lb3) - 1), zr = u >> lb3;
+            tile[co * CS + zr * b3 + 2 * p3 + shift] = activate(acc[mt][0][r] + bv, A.act);
+          }
+        __syncthreads();
+        const int lq = lb3 - 1;                                  // log2(16-byte pieces per row) = log2(b3 / 4)
+        const int per_ch = rows << lq;
+        for (int q = threadIdx.x; q < 8 * per_ch; q += kBlock) {
+          const int c = q / per_ch, rem = q - c * per_ch;
+          int zr = rem >> lq;
+          const int c4 = rem & ((1 << lq) - 1);
+          const acc_t v = *reinterpret_cast<const acc_t *>(tile + c * CS + zr * b3 + 4 * c4);
+          const int z2 = zr & (A.box[2] - 1);
+          zr >>= A.lbox[2];
+          const int z1 = zr & (A.box[1] - 1);
+          zr >>= A.lbox[1];
+          const int x0 = o[0] + zr, x1 = o[1] + z1, x2 = o[2] + z2, x3 = o[3] + 4 * c4;
+          if (c < A.cout && x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2] && x3 < A.L[3])      // L3 % 4 == 0: whole piece inside
+            *reinterpret_cast<acc_t *>(out_b + int64_t(c) * Vout + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + x3) = v;
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -265,6 +308,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, const int (&o)[
 }
 
 // nf_conv_pipe.hip: 1 = launched (dry: would launch), 0 = layer not eligible (use the one-box kernel), < 0 = error
+int launch_conv_c1(const ConvArgs &A0, int MT, int64_t B, int64_t nboxes, hipStream_t stream);
 int launch_conv_pipe(const ConvArgs &A0, int64_t B, int64_t nboxes, int fuse, hipStream_t stream, bool dry);
 
 }  // namespace nf

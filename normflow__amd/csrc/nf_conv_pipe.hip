@@ -362,7 +362,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_pipe_kernel(ConvArgs A) {
     if (last_chunk) {
       if (!(A.dbg & 32))                                    // dbg 32: timing ablation, no epilogue
       conv_epilogue<T, MT, NT, COMPACT, FUSE>(A, co, cb, int64_t(vb) + int64_t(m) * nb, acc, cur, red, wave, lane);
-      if constexpr (FUSE > 0) __syncthreads();            // `cur` served as scratch; it is staged into next
+      __syncthreads();                                    // `cur` may have served as scratch; it is staged into next
       cb = nb_;
 #pragma unroll
       for (int mu = 0; mu < 4; ++mu) co[mu] = no_[mu];
@@ -450,6 +450,7 @@ int launch_conv_pipe(const ConvArgs &A0, int64_t B, int64_t nboxes, int fuse, hi
   if (rows > 256) return 0;                                 // one lane per row group of a wave (v_readlane)
   if (lds > 160 * 1024) return 0;
   if (fuse && size_t(48) * ((kBlock / kWave) * 2 * 16 + 4) * sizeof(float) > size_t(4) * S * sizeof(float)) return 0;
+  if (A.sh2 && size_t(8) * (2 * (kBlock / kWave) * 2 * 16 + 8) > size_t(4) * S) return 0;   // epilogue scratch = one buffer
   if (dry) return 1;
   const int n = A.nt_total;
   if (fuse) {
@@ -466,6 +467,233 @@ int launch_conv_pipe(const ConvArgs &A0, int64_t B, int64_t nboxes, int fuse, hi
   if (n == 3) return launch_pipe_one<2, 3, 3, false, 0>(A, lds, stream);
   if (n == 2) return launch_pipe_one<2, 2, 3, false, 0>(A, lds, stream);
   return launch_pipe_one<2, 1, 3, false, 0>(A, lds, stream);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// K5c: the first ConvAct layer (ONE input channel, <= 8 output channels, kernel extent 3 on the fastest axis).
+// With two-site column packing (columns 0-7 = the layer at site 2p, columns 8-15 = at site 2p+1) the four taps
+// -1..+2 along the fastest axis ARE the K = 4 of one MFMA: A[site pair][k] = in[row + 2p + k - 1], so a kernel row
+// costs one MFMA per 16 site pairs and the whole layer 27 -- the layer is pure data movement (4 B in, 32 B out
+// per site).  Hence: persistent workgroups, the NROWS weight fragments live in registers for the whole launch,
+// one input plane double-buffered in LDS (wide 16-byte row staging, issued before and committed after the item's
+// arithmetic), and the 8 output planes leave through an LDS transpose as whole 16-byte row pieces.
+// Weights: the K-packed layout of nf_conv.hip for cin = 1 (step = kernel row, k = tap): fragment `row` is the
+// 64 floats at wfrag + 64*row.
+template <int MT, int NROWS>
+__global__ __launch_bounds__(kBlock, 2) void conv_c1_kernel(ConvArgs A) {
+  typedef float T;
+  typedef f32x4 acc_t;
+  extern __shared__ __align__(16) unsigned char smem_c1[];
+  constexpr int nwaves = kBlock / kWave;
+  constexpr int UNITS = nwaves * MT * 16;                   // site pairs per box
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4;
+  const int r0 = A.k[0] >> 1, r1 = A.k[1] >> 1, r2 = A.k[2] >> 1;
+  const int h1 = A.hal[1], h2 = A.hal[2], h3 = A.hal[3];
+  const int R = A.hal[0] * h1 * h2;
+  T *buf = reinterpret_cast<T *>(smem_c1);                  // 2 x S input planes, then the output transpose
+  T *ot = buf + 2 * A.S;
+  const int lb3 = A.lbox[3] - 1;
+  const int b3 = 2 << lb3;
+  const int CS = 2 * UNITS + 8;
+
+  const int nb = gridDim.x;
+  const int vb = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
+  if (vb >= A.nitems) return;
+  const int n_my = int((A.nitems - vb + nb - 1) / nb);
+  auto decode = [&](int it, int &b, int (&o)[4]) {
+    b = it / A.nboxes;
+    int bid = it - b * A.nboxes;
+#pragma unroll
+    for (int mu = 3; mu >= 0; --mu) {
+      o[mu] = (bid % A.nbox[mu]) * A.box[mu];
+      bid /= A.nbox[mu];
+    }
+  };
+  auto rowz_of = [&](int t) {
+    const int z0 = t / (h1 * h2), rem = t - z0 * (h1 * h2);
+    const int z1 = rem / h2, z2 = rem - z1 * h2;
+    return z0 | (z1 << 8) | (z2 << 16);
+  };
+
+  // weights: one register per kernel row
+  T wreg[NROWS];
+#pragma unroll
+  for (int r = 0; r < NROWS; ++r) wreg[r] = static_cast<const T *>(A.wfrag)[r * 64 + lane];
+  const int co = lane & 7, shift = (lane >> 3) & 1;
+  const T bv = (A.bias && co < A.cout) ? static_cast<const T *>(A.bias)[co] : T(0);
+
+  // wide staging state (see conv_pipe_kernel)
+  const int llpr = A.wide_llpr, lpr = 1 << llpr, rpi = 64 >> llpr;
+  const int wk = lane & (lpr - 1);
+  int wpz[4], wdst[4], whalo[4], woff[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    int row = rpi * (nwaves * o + wave) + (lane >> llpr);
+    if (row >= R) row = (lane >> llpr) < R ? (lane >> llpr) : 0;
+    wpz[o] = rowz_of(row);
+    wdst[o] = row * h3 + 1 + 4 * wk;
+    whalo[o] = wk == 0 ? row * h3 + h3 - 1 : (wk == lpr - 1 ? row * h3 : A.S - kSlack + lane);
+  }
+  const T *__restrict__ nsrc = nullptr;
+  auto set_next = [&](int b, const int (&o)[4]) {
+    nsrc = static_cast<const T *>(A.in) + int64_t(b) * A.V;
+#pragma unroll
+    for (int oo = 0; oo < 4; ++oo) {
+      const int x0 = wrap1(o[0] + (wpz[oo] & 255) - r0, A.L[0]);
+      const int x1 = wrap1(o[1] + ((wpz[oo] >> 8) & 255) - r1, A.L[1]);
+      const int x2 = wrap1(o[2] + (wpz[oo] >> 16) - r2, A.L[2]);
+      woff[oo] = ((x0 * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + 4 * wk;
+    }
+  };
+  f32x4 sh[4];
+  auto issue_all = [&]() {
+#pragma unroll
+    for (int oo = 0; oo < 4; ++oo)
+      if (oo < A.wide_no) sh[oo] = *reinterpret_cast<const f32x4 *>(nsrc + woff[oo]);
+  };
+  auto commit_all = [&](T *pl) {
+#pragma unroll
+    for (int oo = 0; oo < 4; ++oo)
+      if (oo < A.wide_no) {
+        const int d = wdst[oo];
+        pl[d] = sh[oo][0]; pl[d + 1] = sh[oo][1]; pl[d + 2] = sh[oo][2]; pl[d + 3] = sh[oo][3];
+        pl[whalo[oo]] = wk == 0 ? sh[oo][0] : sh[oo][3];
+      }
+  };
+
+  // A-fragment bases: lane (pair p3 of row z, k-group g) reads in[row + 2*p3 + g]
+  int abase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int u = ((wave * MT + mt) << 4) + (lane & 15);
+    const int p3 = u & ((1 << lb3) - 1);
+    u >>= lb3;
+    const int z2 = u & (A.box[2] - 1);
+    u >>= A.lbox[2];
+    const int z1 = u & (A.box[1] - 1);
+    u >>= A.lbox[1];
+    abase[mt] = ((u * h1 + z1) * h2 + z2) * h3 + 2 * p3 + g;
+  }
+  auto rowoff = [&](int row) {
+    const int j2 = row % A.k[2], t = row / A.k[2];
+    return (((t / A.k[1]) * h1 + t % A.k[1]) * h2 + j2) * h3;
+  };
+  int roff[NROWS];
+#pragma unroll
+  for (int r = 0; r < NROWS; ++r) roff[r] = rowoff(r);       // uniform; SGPRs / constant-folded adds
+
+  int cb, co4[4];
+  decode(vb, cb, co4);
+  set_next(cb, co4);
+  issue_all();
+  commit_all(buf);
+  __syncthreads();
+
+  for (int m = 0; m < n_my; ++m) {
+    const T *cur = buf + (m & 1) * A.S;
+    int nb_ = cb, no_[4] = {co4[0], co4[1], co4[2], co4[3]};
+    if (m + 1 < n_my) decode(vb + (m + 1) * nb, nb_, no_);
+    set_next(nb_, no_);
+    issue_all();                                             // next item's plane -> registers (last item: re-reads its own)
+    acc_t acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = acc_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < NROWS; ++r)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = Mma<T>::mma(cur[abase[mt] + roff[r]], wreg[r], acc[mt]);
+    // ---- epilogue: bias + activation -> ot[co][box row][x3] -> 16-byte row pieces
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int u = ((wave * MT + mt) << 4) + (g << 2) + r;
+        const int p3 = u & ((1 << lb3) - 1), zr = u >> lb3;
+        ot[co * CS + zr * b3 + 2 * p3 + shift] = activate(acc[mt][r] + bv, A.act);
+      }
+    commit_all(buf + ((m + 1) & 1) * A.S);
+    __syncthreads();                                         // ot complete; next plane complete; everyone done with cur
+    {
+      T *__restrict__ out_b = static_cast<T *>(A.out) + int64_t(cb) * A.cout * A.V;
+      const int lq = lb3 - 1;
+      const int per_ch = (UNITS >> lb3) << lq;
+      for (int q = threadIdx.x; q < 8 * per_ch; q += kBlock) {
+        const int c = q / per_ch, rem = q - c * per_ch;
+        int zr = rem >> lq;
+        const int c4 = rem & ((1 << lq) - 1);
+        const acc_t v = *reinterpret_cast<const acc_t *>(ot + c * CS + zr * b3 + 4 * c4);
+        const int z2 = zr & (A.box[2] - 1);
+        zr >>= A.lbox[2];
+        const int z1 = zr & (A.box[1] - 1);
+        zr >>= A.lbox[1];
+        const int x0 = co4[0] + zr, x1 = co4[1] + z1, x2 = co4[2] + z2, x3 = co4[3] + 4 * c4;
+        if (c < A.cout && x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2] && x3 < A.L[3])
+          *reinterpret_cast<acc_t *>(out_b + int64_t(c) * A.V + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + x3) = v;
+      }
+    }
+    __syncthreads();                                         // ot is free again
+    cb = nb_;
+#pragma unroll
+    for (int mu = 0; mu < 4; ++mu) co4[mu] = no_[mu];
+  }
+}
+
+template <int MT, int NROWS>
+static int launch_c1(const ConvArgs &A, size_t lds, hipStream_t stream) {
+  const void *fn = reinterpret_cast<const void *>(&conv_c1_kernel<MT, NROWS>);
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    ncu = prop.multiProcessorCount;
+  }
+  if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) return -1;
+  int blocks_per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, kBlock, lds) != hipSuccess || blocks_per_cu < 1)
+    blocks_per_cu = 1;
+  int64_t grid = int64_t(blocks_per_cu) * ncu;
+  if (grid > A.nitems) grid = A.nitems;
+  grid = (grid + 7) & ~int64_t(7);
+  hipLaunchKernelGGL((conv_c1_kernel<MT, NROWS>), dim3(unsigned(grid)), dim3(kBlock), lds, stream, A);
+  return 1;
+}
+
+// 1 = launched, 0 = not this kernel's layer, < 0 = error.  `MT` is the box size nf_conv.hip planned (2 or 4).
+int launch_conv_c1(const ConvArgs &A0, int MT, int64_t B, int64_t nboxes, hipStream_t stream) {
+  static const int off = getenv("NF_CONV_PIPE") ? (atoi(getenv("NF_CONV_PIPE")) == 0) : 0;
+  if (off) return 0;
+  ConvArgs A = A0;
+  if (A.cin != 1 || !A.sh2 || A.k[3] != 3 || A.dbg || A.stamps || A.compact) return 0;
+  const int nrows = A.k[0] * A.k[1] * A.k[2];
+  if (nrows != 27 && nrows != 9 && nrows != 3) return 0;
+  const int L3 = A.L[3];
+  if (!(A.nbox[3] == 1 && A.box[3] == L3 && (L3 == 8 || L3 == 16 || L3 == 32 || L3 == 64))) return 0;
+  for (int mu = 0; mu < 4; ++mu) {
+    const int r = A.k[mu] >> 1;
+    if (r > A.L[mu] || A.nbox[mu] * A.box[mu] + r - 1 >= 2 * A.L[mu] || A.hal[mu] > 255) return 0;
+  }
+  int64_t halvol = 1, rows = 1;
+  for (int mu = 0; mu < 4; ++mu) halvol *= A.hal[mu];
+  for (int mu = 0; mu < 3; ++mu) rows *= A.hal[mu];
+  int llpr = 1;
+  while ((4 << llpr) < L3) ++llpr;
+  const int rpi = 64 >> llpr;
+  const int64_t no = (rows + rpi * 4 - 1) / (rpi * 4);
+  if (no > 4) return 0;
+  A.wide_no = int(no); A.wide_llpr = llpr;
+  A.S = (int(halvol) + kSlack + 3) & ~3;
+  A.nitems = B * nboxes;
+  A.nboxes = int(nboxes);
+  if (A.nitems >= (int64_t(1) << 31) - 4096) return -2;
+  const size_t lds = (size_t(2) * A.S + size_t(8) * (2 * (kBlock / kWave) * MT * 16 + 8)) * sizeof(float);
+  if (lds > 160 * 1024) return 0;
+  if (MT == 4) return nrows == 27 ? launch_c1<4, 27>(A, lds, stream) : (nrows == 9 ? launch_c1<4, 9>(A, lds, stream) : launch_c1<4, 3>(A, lds, stream));
+  return nrows == 27 ? launch_c1<2, 27>(A, lds, stream) : (nrows == 9 ? launch_c1<2, 9>(A, lds, stream) : launch_c1<2, 3>(A, lds, stream));
 }
 
 }  // namespace nf

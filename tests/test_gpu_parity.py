@@ -611,6 +611,33 @@ def test_conv_pipelined_kernel_vs_oracle(lattice, cin, cout, B):
         assert comp.shape == want.shape and rel(comp, want) <= tol
 
 
+C1_CASES = [
+    # (lattice, cout, B, act): single input channel, <= 8 output channels, whole-row boxes (L3 in {8,16,32,64})
+    ((8, 8, 8, 32), 8, 12, 'tanh'), ((4, 4, 4, 8), 8, 40, 'tanh'), ((6, 4, 6, 16), 5, 30, None),
+    ((8, 8, 16), 8, 70, 'tanh'), ((12, 32), 3, 50, 'relu'), ((32, 32), 8, 600, 'tanh'),
+]
+
+
+@pytest.mark.parametrize("lattice,cout,B,act", C1_CASES)
+def test_conv_first_layer_kernel_vs_oracle(lattice, cout, B, act):
+    """conv_c1_kernel (first ConvAct layer: the four fastest-axis taps of a site pair are the K of one MFMA,
+    weights in registers, persistent workgroups, LDS-transposed row stores) against the fp64 definition;
+    asserts that this kernel ran."""
+    d = len(lattice)
+    g = torch.Generator(device='cpu').manual_seed(3 + cout + d)
+    x = torch.randn((B, 1) + lattice, generator=g, dtype=torch.float64, device='cpu')
+    w = 0.3 * torch.randn((cout, 1) + (3,) * d, generator=g, dtype=torch.float64, device='cpu')
+    b = torch.randn(cout, generator=g, dtype=torch.float64, device='cpu')
+    ref = O._ACTS[act](O.circular_conv_fast(x, w, b))
+    xd, wd, bd = (t.to(DEV, torch.float32) for t in (x, w, b))
+    out = _hip.conv_layer(xd, wd, bd, _hip.ACT_CODES[act])
+    assert _hip.load().nf_conv_last_path() == 2
+    tol = 1e-6 + 2e-7 * 0.3 * 3 ** d               # fp32 products and accumulation over 3^d taps
+    assert out.shape == ref.shape and rel(out, ref) <= tol
+    out_nb = _hip.conv_layer(xd, wd, None, 0)
+    assert rel(out_nb, O.circular_conv_fast(x, w, None)) <= tol
+
+
 def test_fused_epilogue_on_pipelined_kernel_multi_item():
     """nf_conv_rqs through the persistent kernel with several items per workgroup (the epilogue borrows
     the LDS buffer that the next phase is about to be staged into): vs conv + coupling kernels run
