@@ -115,6 +115,14 @@ struct TapWalk {
   }
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter
+// (s_waitcnt vmcnt(0)): every output store and every staging load still in flight would have to complete at each
+// barrier, which serialises the persistent kernels on memory latency (K5c: same time with and without a two-item
+// prefetch lag until this replaced the barriers).  Global memory written here is never read back by the workgroup.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ void stamp(const ConvArgs &A, int slot) {
   if (A.stamps && threadIdx.x == 0) {
     const unsigned id = blockIdx.y * gridDim.x + blockIdx.x;
@@ -142,7 +150,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, const int (&o)[
     constexpr int C = 3 * M - 2;
     constexpr int UNITS = (kBlock / kWave) * MT * 16;
     constexpr int PU = UNITS + 4;                       // row pitch: 16-B aligned rows
-    __syncthreads();                                    // the input tile is dead from here on
+    lds_barrier();                                    // the input tile is dead from here on
     float *pt = reinterpret_cast<float *>(tile);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -155,7 +163,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, const int (&o)[
         for (int r = 0; r < 4; ++r) v[r] += bv;
         *reinterpret_cast<acc_t *>(reinterpret_cast<T *>(pt) + co * PU + ((wave * MT + mt) << 4) + (g << 2)) = v;
       }
-    __syncthreads();
+    lds_barrier();
     double lacc = 0.0;
     if (threadIdx.x < UNITS) {
       int u = threadIdx.x;
@@ -218,7 +226,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, const int (&o)[
         const int b3 = 2 << lb3, lrows_units = lb3;              // sites per box row; units per row = 1 << lb3
         const int rows = UNITS >> lrows_units;
         const int CS = rows * b3 + 8;                            // channel stride: +8 floats spreads the channels over banks
-        __syncthreads();                                         // every wave is done with the input tile
+        lds_barrier();                                         // every wave is done with the input tile
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -227,7 +235,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, const int (&o)[
             const int p3 = u & ((1 << lb3) - 1), zr = u >> lb3;
             tile[co * CS + zr * b3 + 2 * p3 + shift] = activate(acc[mt][0][r] + bv, A.act);
           }
-        __syncthreads();
+        lds_barrier();
         const int lq = lb3 - 1;                                  // log2(16-byte pieces per row) = log2(b3 / 4)
         const int per_ch = rows << lq;
         for (int q = threadIdx.x; q < 8 * per_ch; q += kBlock) {

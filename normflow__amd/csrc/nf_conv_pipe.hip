@@ -26,6 +26,8 @@ namespace nf {
 constexpr int kGPI = 2;        // row groups (x 4 channels) a wave loads per MFMA-loop iteration
 constexpr int kSlack = 64;     // dwords of slack at the end of every LDS plane: target of masked-off stores
 
+__device__ __forceinline__ constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
+
 __device__ __forceinline__ int wrap1(int v, int L) {      // v in [-L, 2L)
   return v < 0 ? v + L : (v >= L ? v - L : v);
 }
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_pipe_kernel(ConvArgs A) {
     issue(i);
     commit();
   }
-  __syncthreads();
+  lds_barrier();
 
   const int P = n_my * nchunk;
   int q = 0, m = 0;                                       // chunk within the item, item counter
@@ -358,11 +360,11 @@ __global__ __launch_bounds__(kBlock, 2) void conv_pipe_kernel(ConvArgs A) {
     set_next(nb_, no_, last_chunk ? 0 : q + 1, buf + ((p + 1) & 1) * bufsz, last_chunk);
     if constexpr (HOT) phase_mma_hot(cur, q);
     else phase_mma(cur, q, (p + 1 < P && !(A.dbg & 16)) ? nst_full : 0);     // dbg 16: timing ablation, no staging
-    __syncthreads();      // everyone is done reading `cur`; the next phase's planes are complete
+    lds_barrier();      // everyone is done reading `cur`; the next phase's planes are complete
     if (last_chunk) {
       if (!(A.dbg & 32))                                    // dbg 32: timing ablation, no epilogue
       conv_epilogue<T, MT, NT, COMPACT, FUSE>(A, co, cb, int64_t(vb) + int64_t(m) * nb, acc, cur, red, wave, lane);
-      __syncthreads();                                    // `cur` may have served as scratch; it is staged into next
+      lds_barrier();                                    // `cur` may have served as scratch; it is staged into next
       cb = nb_;
 #pragma unroll
       for (int mu = 0; mu < 4; ++mu) co[mu] = no_[mu];
@@ -493,8 +495,8 @@ __global__ __launch_bounds__(kBlock, 2) void conv_c1_kernel(ConvArgs A) {
   const int r0 = A.k[0] >> 1, r1 = A.k[1] >> 1, r2 = A.k[2] >> 1;
   const int h1 = A.hal[1], h2 = A.hal[2], h3 = A.hal[3];
   const int R = A.hal[0] * h1 * h2;
-  T *buf = reinterpret_cast<T *>(smem_c1);                  // 2 x S input planes, then the output transpose
-  T *ot = buf + 2 * A.S;
+  T *buf = reinterpret_cast<T *>(smem_c1);                  // ring of 3 input planes (S floats each), then the output transpose
+  T *ot = buf + 3 * A.S;
   const int lb3 = A.lbox[3] - 1;
   const int b3 = 2 << lb3;
   const int CS = 2 * UNITS + 8;
@@ -542,19 +544,23 @@ __global__ __launch_bounds__(kBlock, 2) void conv_c1_kernel(ConvArgs A) {
     nsrc = static_cast<const T *>(A.in) + int64_t(b) * A.V;
 #pragma unroll
     for (int oo = 0; oo < 4; ++oo) {
+      if (oo >= A.wide_no) break;
       const int x0 = wrap1(o[0] + (wpz[oo] & 255) - r0, A.L[0]);
       const int x1 = wrap1(o[1] + ((wpz[oo] >> 8) & 255) - r1, A.L[1]);
       const int x2 = wrap1(o[2] + (wpz[oo] >> 16) - r2, A.L[2]);
       woff[oo] = ((x0 * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + 4 * wk;
     }
   };
-  f32x4 sh[4];
-  auto issue_all = [&]() {
+  // Two register sets: a plane is issued at the start of item m and committed to the LDS ring at the end of item
+  // m + 1, two items before it is read -- the loads get a whole item of arithmetic and stores to land (committing
+  // in the item that issued them left the layer latency-bound at ~1 TB/s).
+  f32x4 shA[4], shB[4];
+  auto issue_all = [&](f32x4 (&sh)[4]) {
 #pragma unroll
     for (int oo = 0; oo < 4; ++oo)
       if (oo < A.wide_no) sh[oo] = *reinterpret_cast<const f32x4 *>(nsrc + woff[oo]);
   };
-  auto commit_all = [&](T *pl) {
+  auto commit_all = [&](const f32x4 (&sh)[4], T *pl) {
 #pragma unroll
     for (int oo = 0; oo < 4; ++oo)
       if (oo < A.wide_no) {
@@ -585,43 +591,113 @@ __global__ __launch_bounds__(kBlock, 2) void conv_c1_kernel(ConvArgs A) {
 #pragma unroll
   for (int r = 0; r < NROWS; ++r) roff[r] = rowoff(r);       // uniform; SGPRs / constant-folded adds
 
-  int cb, co4[4];
+  // the block's items are nb apart: walk (sample, box coordinates) with mixed-radix counters, no divisions
+  int sb, sc[4];                                            // digits of the step nb
+  {
+    int so_[4];
+    decode(nb, sb, so_);
+#pragma unroll
+    for (int mu = 0; mu < 4; ++mu) sc[mu] = so_[mu];        // already multiplied by the box extent
+  }
+  auto advance = [&](int &b, int (&o)[4]) {
+    int carry = 0;
+#pragma unroll
+    for (int mu = 3; mu >= 0; --mu) {
+      o[mu] += sc[mu] + carry * A.box[mu];
+      const int lim = A.nbox[mu] * A.box[mu];
+      carry = o[mu] >= lim ? 1 : 0;
+      o[mu] -= carry ? lim : 0;
+    }
+    b += sb + carry;
+  };
+  int cb, co4[4], b1, o1[4], b2, o2[4];                     // items m, m + 1, m + 2 (past the end: the last one again)
+  const int last = vb + (n_my - 1) * nb;
   decode(vb, cb, co4);
   set_next(cb, co4);
-  issue_all();
-  commit_all(buf);
-  __syncthreads();
+  issue_all(shA);
+  commit_all(shA, buf);                                      // item 0 -> plane 0
+  b1 = cb;
+#pragma unroll
+  for (int mu = 0; mu < 4; ++mu) o1[mu] = co4[mu];
+  if (n_my > 1) advance(b1, o1);
+  b2 = b1;
+#pragma unroll
+  for (int mu = 0; mu < 4; ++mu) o2[mu] = o1[mu];
+  (void)last;
+  set_next(b1, o1);
+  issue_all(shA);                                            // item 1 -> set A (committed at the end of item 0)
+  lds_barrier();
 
-  for (int m = 0; m < n_my; ++m) {
-    const T *cur = buf + (m & 1) * A.S;
-    int nb_ = cb, no_[4] = {co4[0], co4[1], co4[2], co4[3]};
-    if (m + 1 < n_my) decode(vb + (m + 1) * nb, nb_, no_);
-    set_next(nb_, no_);
-    issue_all();                                             // next item's plane -> registers (last item: re-reads its own)
+  auto do_item = [&](int m, f32x4 (&sh_issue)[4], const f32x4 (&sh_commit)[4]) {
+    const T *cur = buf + (m % 3) * A.S;
+    if (m + 2 < n_my) advance(b2, o2);
+    set_next(b2, o2);
+    if (!(A.dbg & 256)) issue_all(sh_issue);                 // item m + 2 -> registers (dbg 256: timing ablation)
     acc_t acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = acc_t{0.f, 0.f, 0.f, 0.f};
+    if (!(A.dbg & 128)) {                                    // dbg 128: timing ablation
+      // A values are read three kernel rows ahead into named buffers; left to itself the compiler serialises
+      // ds_read -> wait -> MFMA through one register and exposes the LDS latency 27*MT times per item
+      constexpr int NG3 = NROWS / 3;
+      T a0[3][MT], a1[3][MT];
+      auto fetch = [&](T (&a)[3][MT], int g3) {
 #pragma unroll
-    for (int r = 0; r < NROWS; ++r)
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt] = Mma<T>::mma(cur[abase[mt] + roff[r]], wreg[r], acc[mt]);
+          for (int mt = 0; mt < MT; ++mt) a[j][mt] = cur[abase[mt] + roff[3 * g3 + j]];
+      };
+      auto mult = [&](const T (&a)[3][MT], int g3) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = Mma<T>::mma(a[j][mt], wreg[3 * g3 + j], acc[mt]);
+      };
+      fetch(a0, 0);
+#pragma unroll
+      for (int g3 = 0; g3 < NG3; g3 += 2) {
+        if (g3 + 1 < NG3) fetch(a1, g3 + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(a0, g3);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g3 + 1 < NG3) {
+          if (g3 + 2 < NG3) fetch(a0, g3 + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          mult(a1, g3 + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
     // ---- epilogue: bias + activation -> ot[co][box row][x3] -> 16-byte row pieces
+    // (the common activation gets its own straight-line copy: sixteen inlined runtime switches over every
+    //  activation made the item body ~40 KB of code, and the kernel instruction-fetch bound)
+    if (A.act == kActTanh) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mt][r] = fast_tanh(acc[mt][r] + bv);
+    } else {
+#pragma unroll 1
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll 1
+        for (int r = 0; r < 4; ++r) acc[mt][r] = activate(acc[mt][r] + bv, A.act);
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int u = ((wave * MT + mt) << 4) + (g << 2) + r;
         const int p3 = u & ((1 << lb3) - 1), zr = u >> lb3;
-        ot[co * CS + zr * b3 + 2 * p3 + shift] = activate(acc[mt][r] + bv, A.act);
+        ot[co * CS + zr * b3 + 2 * p3 + shift] = acc[mt][r];
       }
-    commit_all(buf + ((m + 1) & 1) * A.S);
-    __syncthreads();                                         // ot complete; next plane complete; everyone done with cur
+    commit_all(sh_commit, buf + ((m + 1) % 3) * A.S);        // item m + 1 (issued one item ago) -> its plane
+    lds_barrier();                                         // ot complete; plane m + 1 complete
     {
       T *__restrict__ out_b = static_cast<T *>(A.out) + int64_t(cb) * A.cout * A.V;
       const int lq = lb3 - 1;
-      const int per_ch = (UNITS >> lb3) << lq;
-      for (int q = threadIdx.x; q < 8 * per_ch; q += kBlock) {
-        const int c = q / per_ch, rem = q - c * per_ch;
+      const int lpc = (ilog2_c(UNITS) - lb3) + lq;          // log2(16-byte pieces per channel)
+      for (int q = threadIdx.x; q < (8 << lpc); q += kBlock) {
+        const int c = q >> lpc, rem = q & ((1 << lpc) - 1);
         int zr = rem >> lq;
         const int c4 = rem & ((1 << lq) - 1);
         const acc_t v = *reinterpret_cast<const acc_t *>(ot + c * CS + zr * b3 + 4 * c4);
@@ -630,14 +706,19 @@ __global__ __launch_bounds__(kBlock, 2) void conv_c1_kernel(ConvArgs A) {
         const int z1 = zr & (A.box[1] - 1);
         zr >>= A.lbox[1];
         const int x0 = co4[0] + zr, x1 = co4[1] + z1, x2 = co4[2] + z2, x3 = co4[3] + 4 * c4;
-        if (c < A.cout && x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2] && x3 < A.L[3])
+        if (c < A.cout && x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2] && x3 < A.L[3] && !(A.dbg & 64))   // dbg 64: timing ablation
           *reinterpret_cast<acc_t *>(out_b + int64_t(c) * A.V + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + x3) = v;
       }
     }
-    __syncthreads();                                         // ot is free again
-    cb = nb_;
+    lds_barrier();                                         // ot is free again
+    cb = b1;
+    b1 = b2;
 #pragma unroll
-    for (int mu = 0; mu < 4; ++mu) co4[mu] = no_[mu];
+    for (int mu = 0; mu < 4; ++mu) { co4[mu] = o1[mu]; o1[mu] = o2[mu]; }
+  };
+  for (int m = 0; m < n_my; m += 2) {
+    do_item(m, shB, shA);
+    if (m + 1 < n_my) do_item(m + 1, shA, shB);
   }
 }
 
@@ -668,7 +749,7 @@ int launch_conv_c1(const ConvArgs &A0, int MT, int64_t B, int64_t nboxes, hipStr
   static const int off = getenv("NF_CONV_PIPE") ? (atoi(getenv("NF_CONV_PIPE")) == 0) : 0;
   if (off) return 0;
   ConvArgs A = A0;
-  if (A.cin != 1 || !A.sh2 || A.k[3] != 3 || A.dbg || A.stamps || A.compact) return 0;
+  if (A.cin != 1 || !A.sh2 || A.k[3] != 3 || (A.dbg & 15) || A.stamps || A.compact) return 0;
   const int nrows = A.k[0] * A.k[1] * A.k[2];
   if (nrows != 27 && nrows != 9 && nrows != 3) return 0;
   const int L3 = A.L[3];
@@ -690,7 +771,7 @@ int launch_conv_c1(const ConvArgs &A0, int MT, int64_t B, int64_t nboxes, hipStr
   A.nitems = B * nboxes;
   A.nboxes = int(nboxes);
   if (A.nitems >= (int64_t(1) << 31) - 4096) return -2;
-  const size_t lds = (size_t(2) * A.S + size_t(8) * (2 * (kBlock / kWave) * MT * 16 + 8)) * sizeof(float);
+  const size_t lds = (size_t(3) * A.S + size_t(8) * (2 * (kBlock / kWave) * MT * 16 + 8)) * sizeof(float);
   if (lds > 160 * 1024) return 0;
   if (MT == 4) return nrows == 27 ? launch_c1<4, 27>(A, lds, stream) : (nrows == 9 ? launch_c1<4, 9>(A, lds, stream) : launch_c1<4, 3>(A, lds, stream));
   return nrows == 27 ? launch_c1<2, 27>(A, lds, stream) : (nrows == 9 ? launch_c1<2, 9>(A, lds, stream) : launch_c1<2, 3>(A, lds, stream));
