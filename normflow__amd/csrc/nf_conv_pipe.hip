@@ -32,6 +32,30 @@ __device__ __forceinline__ int wrap1(int v, int L) {      // v in [-L, 2L)
   return v < 0 ? v + L : (v >= L ? v - L : v);
 }
 
+// The NV = K3*NT weight values a lane needs for one kernel row and channel quad: whole 16-byte words plus a
+// remainder loaded at its own width.  (Loading the zero padding of the row record as well looks harmless, but the
+// compiler treats the padding registers as dead, reuses them at once as temporaries and must then WAIT for the load
+// that is still going to overwrite them: a full L2 latency exposed in every iteration.)
+template <int NV> struct BFrag {
+  static constexpr int N4 = NV / 4, NR = NV % 4;
+  f32x4 v4[N4 > 0 ? N4 : 1];
+  float r[NR > 0 ? NR : 1];
+  __device__ __forceinline__ void load(const float *__restrict__ p) {
+#pragma unroll
+    for (int i = 0; i < N4; ++i) v4[i] = *reinterpret_cast<const f32x4 *>(p + 4 * i);
+    if constexpr (NR == 1) {
+      r[0] = p[4 * N4];
+    } else if constexpr (NR == 2) {
+      const float2 t = *reinterpret_cast<const float2 *>(p + 4 * N4);
+      r[0] = t.x; r[1] = t.y;
+    } else if constexpr (NR == 3) {
+      const float2 t = *reinterpret_cast<const float2 *>(p + 4 * N4);
+      r[0] = t.x; r[1] = t.y; r[2] = p[4 * N4 + 2];
+    }
+  }
+  __device__ __forceinline__ float get(int idx) const { return idx < 4 * N4 ? v4[idx >> 2][idx & 3] : r[idx - 4 * N4]; }
+};
+
 template <int MT, int NT, int K3, bool COMPACT, int FUSE, bool WIDE, bool HOT>
 __global__ __launch_bounds__(kBlock, 2) void conv_pipe_kernel(ConvArgs A) {
   static_assert(!HOT || WIDE, "the unrolled schedule is written for wide staging");
@@ -198,11 +222,12 @@ __global__ __launch_bounds__(kBlock, 2) void conv_pipe_kernel(ConvArgs A) {
   // one kernel row and channel quad are adjacent, so a row costs NV4 16-byte loads instead of K3*NT 4-byte ones
   // (probe: tools/mfma_probe2.hip -- the per-fragment dword loads, not the MFMAs, capped the rate)
   constexpr int NV4 = (K3 * NT + 3) / 4;
-  const f32x4 *__restrict__ wrow = static_cast<const f32x4 *>(A.wfrag) + lane * NV4;
+  const float *__restrict__ wrow = static_cast<const float *>(A.wfrag) + lane * (4 * NV4);
+  typedef BFrag<K3 * NT> bfrag_t;
   acc_t acc[MT][NT];
   auto phase_mma = [&](const T *tile, int kq0, int nst) {
     T a0[K3][MT], a1[K3][MT];
-    f32x4 b0[NV4], b1[NV4];
+    bfrag_t b0, b1;
     int j1 = 0, j2 = 0, off = 0, row = 0;
     auto next = [&]() {
       if (row + 1 >= nrows) return;
@@ -217,10 +242,8 @@ __global__ __launch_bounds__(kBlock, 2) void conv_pipe_kernel(ConvArgs A) {
         }
       }
     };
-    auto request = [&](T (&a)[K3][MT], f32x4 (&b)[NV4]) {
-      const f32x4 *__restrict__ wt = wrow + (int64_t(row) * A.kq_total + kq0) * (64 * NV4);
-#pragma unroll
-      for (int i = 0; i < NV4; ++i) b[i] = wt[i];
+    auto request = [&](T (&a)[K3][MT], bfrag_t &b) {
+      b.load(wrow + (int64_t(row) * A.kq_total + kq0) * (256 * NV4));
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const T *pa = tile + abase[mt] + off;
@@ -228,14 +251,14 @@ __global__ __launch_bounds__(kBlock, 2) void conv_pipe_kernel(ConvArgs A) {
         for (int j3 = 0; j3 < K3; ++j3) a[j3][mt] = pa[j3];
       }
     };
-    auto multiply = [&](const T (&a)[K3][MT], const f32x4 (&b)[NV4]) {
+    auto multiply = [&](const T (&a)[K3][MT], const bfrag_t &b) {
 #pragma unroll
       for (int j3 = 0; j3 < K3; ++j3)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = Mma<T>::mma(a[j3][mt], b[(j3 * NT + nt) >> 2][(j3 * NT + nt) & 3], acc[mt][nt]);
+            acc[mt][nt] = Mma<T>::mma(a[j3][mt], b.get(j3 * NT + nt), acc[mt][nt]);
     };
     request(a0, b0);
     int r = 0, i = 0;
@@ -282,13 +305,11 @@ __global__ __launch_bounds__(kBlock, 2) void conv_pipe_kernel(ConvArgs A) {
   constexpr int kLag = 3;
   auto phase_mma_hot = [&](const T *tile, int kq0) {
     T a0[K3][MT], a1[K3][MT];
-    f32x4 b0[NV4], b1[NV4];
+    bfrag_t b0, b1;
     f32x4 sh[8];
     auto rowoff = [&](int row) { return (((row / 9) * h1 + (row / 3) % 3) * h2 + row % 3) * h3; };
-    auto request = [&](T (&a)[K3][MT], f32x4 (&b)[NV4], int row) {
-      const f32x4 *__restrict__ wt = wrow + (int64_t(row) * A.kq_total + kq0) * (64 * NV4);
-#pragma unroll
-      for (int i = 0; i < NV4; ++i) b[i] = wt[i];
+    auto request = [&](T (&a)[K3][MT], bfrag_t &b, int row) {
+      b.load(wrow + (int64_t(row) * A.kq_total + kq0) * (256 * NV4));
       const int off = rowoff(row);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -297,14 +318,14 @@ __global__ __launch_bounds__(kBlock, 2) void conv_pipe_kernel(ConvArgs A) {
         for (int j3 = 0; j3 < K3; ++j3) a[j3][mt] = pa[j3];
       }
     };
-    auto multiply = [&](const T (&a)[K3][MT], const f32x4 (&b)[NV4]) {
+    auto multiply = [&](const T (&a)[K3][MT], const bfrag_t &b) {
 #pragma unroll
       for (int j3 = 0; j3 < K3; ++j3)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = Mma<T>::mma(a[j3][mt], b[(j3 * NT + nt) >> 2][(j3 * NT + nt) & 3], acc[mt][nt]);
+            acc[mt][nt] = Mma<T>::mma(a[j3][mt], b.get(j3 * NT + nt), acc[mt][nt]);
     };
     request(a0, b0, 0);
 #pragma unroll
