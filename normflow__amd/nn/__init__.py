@@ -8,3 +8,5 @@ from .scalar.modules_ import Expit_, Logit_, SplineNet_, ScaleNet_, SgnBiasNet_
 
 from .scalar.couplings_ import Coupling_, ShiftCoupling_, AffineCoupling_
 from .scalar.couplings_ import RQSplineCoupling_, MultiRQSplineCoupling_
+
+from .scalar.spectral_ import FFTNet_, MeanFieldNet_, PSDBlock_, IPSD, lattice_k2
