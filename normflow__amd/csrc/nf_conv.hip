@@ -525,6 +525,7 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
     for (int mu = 0; mu < 4; ++mu) { cap[mu] = 1 << ilog2(A.L[mu]); box[mu] = 1; }
     box[3] = cap[3] < box3_cap ? cap[3] : box3_cap;
     const int min3 = (compact || A.sh2) ? 8 : 4;            // >= 4 units along the fastest axis
+    while (box[3] > min3 && A.L[3] % box[3] != 0) box[3] >>= 1;   // prefer boxes that tile the fastest axis (48 -> 3 x 16)
     if (box[3] < min3) box[3] = min3;
     int vol = box[3];
     while (vol < target) {

@@ -407,6 +407,50 @@ def test_config4_full_lattice_properties():
     _big_properties((32, 32, 32, 32), 8, 16, torch.float32)
 
 
+def _network_properties(shape, B, kinds, m=16):
+    """Whole coupling blocks on a full-size lattice through the package API (ConvAct nets on the MFMA kernels,
+    fused last layer under no_grad): size-independent properties -- fused inference == the differentiable
+    (unfused) path, inverse(forward) = id with cancelling log-Jacobians, samples independent (bitwise)."""
+    torch.manual_seed(9)
+    d = len(shape)
+    dt = torch.float32
+    mask = EvenOddMask(shape=shape)
+    lim = dict(xlim=(-5.0, 5.0), ylim=(-5.0, 5.0), extrap={'left': 'linear', 'right': 'linear'})
+    blocks = []
+    for kind in kinds:
+        C = 3 * m - 2 if kind == 'rqs' else 2
+        nets = [ConvAct(1, C, 3, conv_dim=d, hidden_sizes=[8, 8], acts=['tanh', 'tanh', None]) for _ in range(2)]
+        for net in nets:
+            with torch.no_grad():
+                for p in list(net.parameters())[-2:]:
+                    p.mul_(0.3)
+        blocks.append(RQSplineCoupling_(nets, mask=mask, **lim) if kind == 'rqs' else AffineCoupling_(nets, mask=mask))
+    net_ = ModuleList_(blocks)
+    net_.to(device=DEV, dtype=dt)
+    x = torch.randn((B,) + shape, device=DEV, dtype=dt)
+    with torch.no_grad():
+        y, lj = net_(x)
+        xb, lb = net_.backward(y, lj)
+        perm = torch.randperm(B, device=DEV)
+        yp, ljp = net_(x[perm])
+    assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(lj).all())
+    assert rel(xb, x) <= 2e-4 and float(lb.abs().max()) <= 2e-5 * max(1.0, float(lj.abs().max())) * 50
+    assert torch.equal(yp, y[perm]) and torch.equal(ljp, lj[perm])
+    y2, lj2 = net_(x[:1].clone().requires_grad_(True))        # differentiable path: logits materialised, K2 kernel
+    assert rel(y2, y[:1]) <= 5e-6 and rel(lj2, lj[:1]) <= 5e-6
+
+
+def test_config4_network_properties():
+    """BASELINE config 4 blocks (32^4, RQ-spline m=16, ConvAct 1-8-8-46) at a small batch."""
+    _network_properties((32, 32, 32, 32), 3, ['rqs', 'rqs'])
+
+
+def test_config5_lattice_network_properties():
+    """BASELINE config 5 lattice (48^4 -- not a power of two: clipped boxes, narrow staging) with mixed
+    affine + spline blocks, fp32."""
+    _network_properties((48, 48, 48, 48), 2, ['affine', 'rqs'])
+
+
 def test_posterior_sample_and_sanity_on_lattice():
     """Model.posterior.sample / log_prob / backward_sanitychecker unchanged on a 2-D lattice
     with mixed blocks (BASELINE config 2 shapes: 16x16, affine)."""

@@ -1,0 +1,51 @@
+"""Throughput of the BASELINE.json configurations other than the bench's (parity-test cases; one GPU, fp32,
+forward + log|det J| under no_grad, synthetic inputs).  python tools/config_bench.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("NORMFLOW_AMD_KEEP_TORCH_DEFAULTS", "1")
+import torch
+from normflow__amd.nn import ConvAct, RQSplineCoupling_, AffineCoupling_, ModuleList_
+from normflow__amd.mask import EvenOddMask
+
+DEV = torch.device("cuda:0")
+
+
+def build(shape, kinds, m=16):
+    d = len(shape)
+    mask = EvenOddMask(shape=shape)
+    lim = dict(xlim=(-5.0, 5.0), ylim=(-5.0, 5.0), extrap={'left': 'linear', 'right': 'linear'})
+    blocks = []
+    for kind in kinds:
+        C = 3 * m - 2 if kind == 'rqs' else 2
+        net = ConvAct(1, C, 3, conv_dim=d, hidden_sizes=[8, 8], acts=['tanh', 'tanh', None])
+        with torch.no_grad():
+            for p in list(net.parameters())[-2:]:
+                p.mul_(0.3)
+        blocks.append(RQSplineCoupling_([net], mask=mask, **lim) if kind == 'rqs' else AffineCoupling_([net], mask=mask))
+    return ModuleList_(blocks).to(device=DEV, dtype=torch.float32)
+
+
+def run(name, shape, kinds, B, reps=3):
+    torch.manual_seed(0)
+    net = build(shape, kinds)
+    x = torch.randn((B,) + shape, device=DEV, dtype=torch.float32)
+    with torch.no_grad():
+        net(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            net(x)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    sites = B
+    for n in shape:
+        sites *= n
+    print(f"{name:34s} B={B:5d}  {dt * 1e3:9.2f} ms/step  {B / dt:10.1f} configs/s  {sites * len(kinds) / dt / 1e9:7.2f} Gsite-layers/s")
+
+
+if __name__ == "__main__":
+    run("c2 16x16, 4 affine", (16, 16), ['affine'] * 4, 512, reps=20)
+    run("c3 16^3, 8 rqs m=16", (16, 16, 16), ['rqs'] * 8, 1024)
+    run("c4 32^4, 8 rqs (per-GPU share)", (32,) * 4, ['rqs'] * 8, 128)
+    run("c5 48^4, 8 affine + 8 rqs", (48,) * 4, ['affine', 'rqs'] * 8, 8)
+    run("   32^4, 8 affine + 8 rqs", (32,) * 4, ['affine', 'rqs'] * 8, 40)
