@@ -863,3 +863,32 @@ def test_example_network_assembles_and_trains():
     model.fit(n_epochs=40, batch_size=128, hyperparam=dict(lr=0.01), checkpoint_dict=dict(print_stride=1000))
     h = model.fit.train_history['loss']
     assert h[-1] < h[0] - 0.5
+
+
+def test_graphed_flow_replays_bitwise():
+    """GraphedFlow (one no_grad pass captured into a HIP graph) == the eager pass, bitwise, on new inputs,
+    forward and backward; shape changes are refused.  (BASELINE config 2 shapes: launch-bound.)"""
+    from normflow__amd import GraphedFlow
+    torch.manual_seed(2)
+    shape = (16, 16)
+    mask = EvenOddMask(shape=shape)
+    mk = lambda c: ConvAct(1, c, 3, conv_dim=2, hidden_sizes=[8, 8], acts=['tanh', 'tanh', None])
+    net_ = ModuleList_([AffineCoupling_([mk(2) for _ in range(4)], mask=mask),
+                        RQSplineCoupling_([mk(22), mk(22)], mask=mask, xlim=(-5, 5), ylim=(-5, 5),
+                                          extrap={'left': 'linear', 'right': 'linear'})])
+    net_.to(device=DEV, dtype=torch.float32)
+    x = torch.randn((64,) + shape, device=DEV, dtype=torch.float32)
+    fwd = GraphedFlow(net_, x)
+    for _ in range(2):
+        xn = torch.randn_like(x)
+        with torch.no_grad():
+            y0, l0 = net_(xn)
+        y1, l1 = fwd(xn)
+        assert torch.equal(y0, y1) and torch.equal(l0, l1)
+    bwd = GraphedFlow(net_, y0, inverse=True, log0=l0)
+    xb, lb = bwd(y0, l0)
+    with torch.no_grad():
+        xe, le = net_.backward(y0, l0)
+    assert torch.equal(xb, xe) and torch.equal(lb, le)
+    with pytest.raises(ValueError):
+        fwd(x[:8])
