@@ -42,7 +42,9 @@ extern "C" {
 
 #define NF_VERSION 100 /* 0.1.0 */
 
-enum nf_dtype { NF_F32 = 0, NF_F64 = 1 };
+/* NF_F16 (nf_rqs_fwd / nf_rqs_inv only, knots_len 4/8/16): x, params and y are IEEE half, the arithmetic is fp32 and
+ * log0 / logj are fp32 ("fp16 params / fp32 log-det accumulate", BASELINE config 5). */
+enum nf_dtype { NF_F32 = 0, NF_F64 = 1, NF_F16 = 2 };
 enum nf_layout { NF_LAYOUT_FULL = 0, NF_LAYOUT_PAIR = 1 };
 enum nf_extrap { NF_EXTRAP_NONE = 0, NF_EXTRAP_LINEAR = 1, NF_EXTRAP_ANTI = 2 };
 enum nf_status {

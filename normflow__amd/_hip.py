@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnormflow_hip.so")
 
-NF_F32, NF_F64 = 0, 1
+NF_F32, NF_F64, NF_F16 = 0, 1, 2
 LAYOUT_FULL, LAYOUT_PAIR = 0, 1
 EXTRAP = {None: 0, 'none': 0, 'linear': 1, 'anti': 2, 'anti-periodic': 2}
 
@@ -105,7 +105,9 @@ def _dtype_code(t):
         return NF_F32
     if t.dtype == torch.float64:
         return NF_F64
-    raise TypeError(f"normflow__amd kernels support float32 and float64, got {t.dtype}")
+    if t.dtype == torch.float16:      # storage only (RQ-spline map kernels): fp32 arithmetic, fp32 log-det
+        return NF_F16
+    raise TypeError(f"normflow__amd kernels support float32 and float64 (and float16 storage for the spline map), got {t.dtype}")
 
 
 def _require_device(*tensors):
@@ -176,7 +178,9 @@ def make_rqs_opts(m, xlim, ylim, extrap, layout, knots_x=None, knots_y=None):
 def _rqs_call(fn_name, v, params, mask, log0, opts, strides, B, V):
     lib = load()
     out = torch.empty_like(v)
-    logj = torch.empty(B, dtype=v.dtype, device=v.device)
+    logj = torch.empty(B, dtype=torch.float32 if v.dtype == torch.float16 else v.dtype, device=v.device)
+    if log0 is not None and log0.dtype != logj.dtype:
+        raise TypeError(f"log0 must be {logj.dtype} for a {v.dtype} field")
     ws = _workspace(min(B, MAX_B), V, v.device)
     for b0 in range(0, B, MAX_B):
         b1 = min(B, b0 + MAX_B)
@@ -224,6 +228,8 @@ class RQSCouplingFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout, glogj):
         x, params, mask = ctx.saved_tensors
+        if x.dtype == torch.float16:
+            raise NotImplementedError("fp16 storage is an inference path (nf_rqs_fwd / nf_rqs_inv); train in fp32")
         B, V = x.shape
         gin, gpar = _rqs_vjp_call("nf_rqs_inv_vjp" if ctx.inverse else "nf_rqs_fwd_vjp", x, params, mask,
                                   gout.contiguous(), glogj.contiguous(), ctx.opts, None, B, V)

@@ -17,6 +17,7 @@
 //              interior knots strictly below the value)
 //   evaluate   src/lib/spline/spline.py:185-220 ; invert :222-287 (stable root)
 //   log-det    src/nn/scalar/couplings_.py:186-188, src/nn/_core.py:38-42
+#include <type_traits>
 #include "nf_rqs_core.h"
 
 namespace nf {
@@ -44,16 +45,18 @@ struct RqsArgs {
 // ------------------------------------------------------------------ kernels
 // Unit -> (site, parameter column).  PAIR: unit h covers sites 2h, 2h+1 and the
 // active one is read from the mask; FULL: unit = site.
-template <typename T, int MT, int MODE, bool PAIR>
+// T = arithmetic type, S = storage type of x, params and y (S = T, or S = __half with T = float: BASELINE config 5,
+// "fp16 params / fp32 log-det accumulate" -- half the HBM bytes per site, log-det partials in double as always).
+template <typename T, typename S, int MT, int MODE, bool PAIR>
 __global__ __launch_bounds__(kBlock) void rqs_kernel(RqsArgs A) {
   constexpr int C = MT > 0 ? 3 * MT - 2 : 1;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   __shared__ double red[kBlock / kWave];
   const int b = blockIdx.y;
   const int C_rt = A.C;
-  const T *__restrict__ xin = static_cast<const T *>(A.x) + int64_t(b) * A.x_bs;
-  const T *__restrict__ par = static_cast<const T *>(A.params) + int64_t(b) * A.p_bs;
-  T *__restrict__ yout = static_cast<T *>(A.y) + int64_t(b) * A.y_bs;
+  const S *__restrict__ xin = static_cast<const S *>(A.x) + int64_t(b) * A.x_bs;
+  const S *__restrict__ par = static_cast<const S *>(A.params) + int64_t(b) * A.p_bs;
+  S *__restrict__ yout = static_cast<S *>(A.y) + int64_t(b) * A.y_bs;
   double acc = 0.0;
   const int64_t base = int64_t(blockIdx.x) * blockDim.x * A.iters + threadIdx.x;
   for (int it = 0; it < A.iters; ++it) {
@@ -66,32 +69,32 @@ __global__ __launch_bounds__(kBlock) void rqs_kernel(RqsArgs A) {
       const uint16_t mk = reinterpret_cast<const uint16_t *>(A.mask)[u];
       off = (mk & 0xff) ? 0 : 1;
       active = true;
-      const typename Pair2<T>::type xv = reinterpret_cast<const typename Pair2<T>::type *>(xin)[u];
-      v = off ? xv.y : xv.x;
+      const typename Pair2<S>::type xv = reinterpret_cast<const typename Pair2<S>::type *>(xin)[u];
+      v = T(off ? xv.y : xv.x);
     } else {
       active = A.mask[u] != 0;
-      v = xin[u];
+      v = T(xin[u]);
     }
     if (active) {
       if constexpr (MT > 0) {
         RegCol<T, C> a;
 #pragma unroll
-        for (int c = 0; c < C; ++c) a[c] = par[int64_t(c) * A.Vp + u];
+        for (int c = 0; c < C; ++c) a[c] = T(par[int64_t(c) * A.Vp + u]);
         rqs_site<T, MT, MODE == kInv>(a, A.P, v, val, logd);
       } else {
         LdsCol<T> a{reinterpret_cast<T *>(smem_raw) + threadIdx.x, int(blockDim.x)};
-        for (int c = 0; c < C_rt; ++c) a[c] = par[int64_t(c) * A.Vp + u];
+        for (int c = 0; c < C_rt; ++c) a[c] = T(par[int64_t(c) * A.Vp + u]);
         rqs_site<T, 0, MODE == kInv>(a, A.P, v, val, logd);
       }
     }
     if (PAIR) {
       // write the pair: transformed value at the active site, 0 at the frozen one
-      typename Pair2<T>::type o;
-      o.x = off ? T(0) : val;
-      o.y = off ? val : T(0);
-      reinterpret_cast<typename Pair2<T>::type *>(yout)[u] = o;
+      typename Pair2<S>::type o;
+      o.x = S(off ? T(0) : val);
+      o.y = S(off ? val : T(0));
+      reinterpret_cast<typename Pair2<S>::type *>(yout)[u] = o;
     } else {
-      yout[u] = val;
+      yout[u] = S(val);
     }
     acc += double(logd);
   }
@@ -217,7 +220,7 @@ template <typename T> static int pick_block(const RqsArgs &A) {
   return col * block <= 160 * 1024 ? block : 0;
 }
 
-template <typename T, int MODE, bool VJP>
+template <typename T, typename S, int MODE, bool VJP>
 static int dispatch(const RqsArgs &A, dim3 grid, int block, hipStream_t stream) {
   const bool pair = A.layout == NF_LAYOUT_PAIR;
 #define NF_CASE(MV)                                                                         \
@@ -226,13 +229,17 @@ static int dispatch(const RqsArgs &A, dim3 grid, int block, hipStream_t stream) 
       if (pair) hipLaunchKernelGGL((rqs_vjp_kernel<T, MV, MODE, true>), grid, dim3(kBlock), 0, stream, A);  \
       else hipLaunchKernelGGL((rqs_vjp_kernel<T, MV, MODE, false>), grid, dim3(kBlock), 0, stream, A);      \
     } else {                                                                                \
-      if (pair) hipLaunchKernelGGL((rqs_kernel<T, MV, MODE, true>), grid, dim3(kBlock), 0, stream, A);      \
-      else hipLaunchKernelGGL((rqs_kernel<T, MV, MODE, false>), grid, dim3(kBlock), 0, stream, A);          \
+      if (pair) hipLaunchKernelGGL((rqs_kernel<T, S, MV, MODE, true>), grid, dim3(kBlock), 0, stream, A);   \
+      else hipLaunchKernelGGL((rqs_kernel<T, S, MV, MODE, false>), grid, dim3(kBlock), 0, stream, A);       \
     }                                                                                       \
     return check_launch("rqs kernel");                                                      \
   }
   NF_STATIC_M(NF_CASE)
 #undef NF_CASE
+  if constexpr (!std::is_same<T, S>::value) {
+    set_error("nf_rqs: fp16 storage is built for knots_len 4, 8 and 16 without fixed knots");
+    return NF_EINVAL;
+  } else {
   const size_t lds = size_t(A.C) * sizeof(T) * block;
 #define NF_LDS_LAUNCH(KERNEL)                                                                     \
   do {                                                                                            \
@@ -245,14 +252,15 @@ static int dispatch(const RqsArgs &A, dim3 grid, int block, hipStream_t stream) 
     if (pair) NF_LDS_LAUNCH((rqs_vjp_kernel<T, 0, MODE, true>));
     else NF_LDS_LAUNCH((rqs_vjp_kernel<T, 0, MODE, false>));
   } else {
-    if (pair) NF_LDS_LAUNCH((rqs_kernel<T, 0, MODE, true>));
-    else NF_LDS_LAUNCH((rqs_kernel<T, 0, MODE, false>));
+    if (pair) NF_LDS_LAUNCH((rqs_kernel<T, T, 0, MODE, true>));
+    else NF_LDS_LAUNCH((rqs_kernel<T, T, 0, MODE, false>));
   }
 #undef NF_LDS_LAUNCH
   return check_launch("rqs kernel (lds)");
+  }
 }
 
-template <typename T, int MODE>
+template <typename T, typename S, int MODE>
 static int run_map(const void *in, const void *params, const uint8_t *mask, const void *log0, void *out,
                    void *logj, int64_t B, int64_t V, const nf_rqs_opts *o, const nf_strides *st,
                    void *ws, size_t ws_bytes, hipStream_t stream) {
@@ -273,7 +281,7 @@ static int run_map(const void *in, const void *params, const uint8_t *mask, cons
   A.x = in; A.params = params; A.y = out; A.partial = static_cast<double *>(ws);
   A.iters = t.iters;
   if (t.blocks_x > 0) {
-    rc = dispatch<T, MODE, false>(A, dim3(unsigned(t.blocks_x), unsigned(B)), block, stream);
+    rc = dispatch<T, S, MODE, false>(A, dim3(unsigned(t.blocks_x), unsigned(B)), block, stream);
     if (rc) return rc;
   }
   return launch_finalize<T>(A.partial, t.blocks_x, log0, logj, B, stream);
@@ -293,7 +301,7 @@ static int run_vjp(const void *x, const void *params, const uint8_t *mask, const
   const Tiling t = make_tiling(A.units, B, block);
   A.x = x; A.params = params; A.grad_out = grad_out; A.grad_logj = grad_logj;
   A.grad_in = grad_in; A.grad_params = grad_params; A.iters = t.iters;
-  return dispatch<T, MODE, true>(A, dim3(unsigned(t.blocks_x), unsigned(B)), block, stream);
+  return dispatch<T, T, MODE, true>(A, dim3(unsigned(t.blocks_x), unsigned(B)), block, stream);
 }
 
 }  // namespace nf
@@ -305,8 +313,9 @@ extern "C" int nf_rqs_fwd(const void *x, const void *params, const uint8_t *mask
                           const nf_strides *strides, void *workspace, size_t workspace_bytes,
                           int dtype, void *stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dtype == NF_F32) return run_map<float, kFwd>(x, params, mask, log0, y, logj, B, V, opts, strides, workspace, workspace_bytes, s);
-  if (dtype == NF_F64) return run_map<double, kFwd>(x, params, mask, log0, y, logj, B, V, opts, strides, workspace, workspace_bytes, s);
+  if (dtype == NF_F32) return run_map<float, float, kFwd>(x, params, mask, log0, y, logj, B, V, opts, strides, workspace, workspace_bytes, s);
+  if (dtype == NF_F64) return run_map<double, double, kFwd>(x, params, mask, log0, y, logj, B, V, opts, strides, workspace, workspace_bytes, s);
+  if (dtype == NF_F16) return run_map<float, __half, kFwd>(x, params, mask, log0, y, logj, B, V, opts, strides, workspace, workspace_bytes, s);
   set_error("nf_rqs_fwd: unsupported dtype %d", dtype);
   return NF_EINVAL;
 }
@@ -316,8 +325,9 @@ extern "C" int nf_rqs_inv(const void *y, const void *params, const uint8_t *mask
                           const nf_strides *strides, void *workspace, size_t workspace_bytes,
                           int dtype, void *stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dtype == NF_F32) return run_map<float, kInv>(y, params, mask, log0, x, logj, B, V, opts, strides, workspace, workspace_bytes, s);
-  if (dtype == NF_F64) return run_map<double, kInv>(y, params, mask, log0, x, logj, B, V, opts, strides, workspace, workspace_bytes, s);
+  if (dtype == NF_F32) return run_map<float, float, kInv>(y, params, mask, log0, x, logj, B, V, opts, strides, workspace, workspace_bytes, s);
+  if (dtype == NF_F64) return run_map<double, double, kInv>(y, params, mask, log0, x, logj, B, V, opts, strides, workspace, workspace_bytes, s);
+  if (dtype == NF_F16) return run_map<float, __half, kInv>(y, params, mask, log0, x, logj, B, V, opts, strides, workspace, workspace_bytes, s);
   set_error("nf_rqs_inv: unsupported dtype %d", dtype);
   return NF_EINVAL;
 }

@@ -3,6 +3,7 @@
 // Shared by the stand-alone coupling kernels (nf_rqs.hip) and by the conv kernel's fused
 // epilogue (nf_conv.hip).  Reference lines restated: see the header of nf_rqs.hip.
 #pragma once
+#include <hip/hip_fp16.h>
 #include "nf_internal.h"
 
 namespace nf {
@@ -28,6 +29,7 @@ template <typename T> struct LdsCol {          // runtime m: one LDS column per 
 template <typename T> struct Pair2;   // two adjacent sites as one 8/16-byte access
 template <> struct Pair2<float> { typedef float2 type; };
 template <> struct Pair2<double> { typedef double2 type; };
+template <> struct Pair2<__half> { typedef __half2 type; };
 
 template <typename T> struct Site {   // what the scan selects for one site
   T x0, y0, bw, bh, c0, c1, xe, ye;

@@ -892,3 +892,36 @@ def test_graphed_flow_replays_bitwise():
     assert torch.equal(xb, xe) and torch.equal(lb, le)
     with pytest.raises(ValueError):
         fwd(x[:8])
+
+
+@pytest.mark.parametrize("m,layout", [(16, "pair"), (16, "full"), (8, "pair"), (4, "full")])
+def test_rqs_fp16_storage_fp32_logdet(m, layout):
+    """BASELINE config 5 precision: x, logits and y stored in fp16, arithmetic fp32, log-det accumulated in
+    fp32 (nf_dtype NF_F16).  Against the fp64 oracle ON THE SAME fp16-rounded inputs: y to fp16 output rounding
+    (2^-11 relative), log|J| to the fp32 tolerance 1e-5; inverse by forward residual; byte-for-byte the same result as the
+    fp32 kernel fed the fp16-rounded inputs, up to the final rounding of y."""
+    torch.manual_seed(m)
+    shape = (8, 8, 8, 16)
+    B, V = 6, int(np.prod(shape))
+    C = 3 * m - 2
+    lim = dict(xlim=(-5.0, 5.0), ylim=(-5.0, 5.0), extrap={'left': 'linear', 'right': 'linear'})
+    mask = EvenOddMask(shape=shape)
+    act = mask.activity(0).reshape(-1).to(DEV)
+    x16 = (1.5 * torch.randn(B, V, device=DEV)).half() * act.half()
+    pfull = (0.5 * torch.randn(B, C, V, device=DEV)).half()
+    p16 = compact(pfull, act) if layout == "pair" else pfull
+    lay = _hip.LAYOUT_PAIR if layout == "pair" else _hip.LAYOUT_FULL
+    opts = _hip.make_rqs_opts(m, lim["xlim"], lim["ylim"], lim["extrap"], lay)
+    l0 = torch.randn(B, device=DEV, dtype=torch.float32)
+    y16, lj = _hip.RQSCouplingFn.apply(x16, p16, l0, act, opts, False)
+    assert y16.dtype == torch.float16 and lj.dtype == torch.float32
+    yo, lo = O.rqs_coupling_atom(x16.double().cpu().reshape((B,) + shape), pfull.double().cpu().reshape((B, C) + shape),
+                                 O.channel_mask(shape, 0), log0=l0.double().cpu(), **lim)
+    assert rel(y16.reshape((B,) + shape), yo) <= 2 ** -10 and rel(lj, lo) <= 1e-5
+    y32, lj32 = _hip.RQSCouplingFn.apply(x16.float(), p16.float(), l0, act, opts, False)
+    assert torch.equal(y16, y32.half()) and torch.equal(lj, lj32)
+    # inverse: y was rounded to fp16, so x comes back only up to 2^-11 / slope; the forward residual is the clean check
+    xb, lb = _hip.RQSCouplingFn.apply(y16, p16, lj, act, opts, True)
+    assert xb.dtype == torch.float16 and bool(torch.isfinite(lb).all())
+    yb, _ = _hip.RQSCouplingFn.apply(xb, p16, None, act, opts, False)
+    assert rel(yb, y16) <= 2 ** -9
