@@ -244,10 +244,21 @@ def main():
                    "in_timed_pipeline": not fused}
         if fused:
             ft = time_fused_last_layer(cpl, lattice, a.knots, dev, max(2, a.kernel_reps // 3), a.batch)
+            # fabric traffic of one launch from the committed PMC profile (separate --pmc passes), quoted only for
+            # the profiled lattice and layer and scaled to this launch's slab
+            ftraffic, ftraffic_src = None, None
+            try:
+                prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv.json")))
+                k = prof["kernels"]["void nf::conv_pipe_kernel<2, 3, 3, true, 1, true, true>(nf::ConvArgs)"]
+                if lattice == (32, 32, 32, 32) and a.knots == 16:
+                    ftraffic = k["traffic_bytes_per_launch"] * ft["slab"] / prof["slab_batch"]
+                    ftraffic_src = "profiles/r01_pmc_conv.json"
+            except (OSError, KeyError, ValueError):
+                pass
             roof = {"kernel": "nf::conv_pipe_kernel<2,3,3,compact,fused-rqs-fwd,wide,unrolled> (last conv layer 8->46 at the active sites "
                               "+ RQ-spline coupling epilogue; dominant kernel of the timed region)",
                     "bound": "mfma", "achieved": ft["tflops"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ft["tflops"] / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                    "frac": ft["tflops"] / MFMA_F32_PEAK_TFLOPS, "traffic": ftraffic, "traffic_source": ftraffic_src,
                     "launch_ms": 1e3 * ft["seconds"], "slab_batch": ft["slab"],
                     "algorithmic_flops_per_launch": ft["flops"]}
         else:
