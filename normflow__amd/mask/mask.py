@@ -28,7 +28,9 @@ class Mask(torch.nn.Module):
 
     def __init__(self, **mask_kwargs):
         super().__init__()
-        m = self.make_mask(**mask_kwargs).to(torch.uint8)
+        # like the reference (mask.py:17-28) the buffers live on torch's DEFAULT device -- 'cuda' once the package is
+        # imported on a GPU box -- so that a net assembled from defaults meets the prior's samples on the same device
+        m = self.make_mask(**mask_kwargs).to(device=torch.get_default_device(), dtype=torch.uint8)
         self.register_buffer('_mask', m)
         self.register_buffer('_c_mask', 1 - m)
         self.mask_kwargs = mask_kwargs

@@ -12,6 +12,7 @@ Tolerances (north_star: "within 1e-5 relative fp32 tolerance"):
                  6e-5, set by the conv's rounding, not the kernels.
 relative = max|a-b| / max(1, max|b|).
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -925,3 +926,20 @@ def test_rqs_fp16_storage_fp32_logdet(m, layout):
     assert xb.dtype == torch.float16 and bool(torch.isfinite(lb).all())
     yb, _ = _hip.RQSCouplingFn.apply(xb, p16, None, act, opts, False)
     assert rel(yb, y16) <= 2 ** -9
+
+
+def test_example_script_runs_with_package_defaults():
+    """examples/phi4_lattice.py in a fresh interpreter: the package's import side effects (default dtype fp64,
+    default device cuda -- the reference's, device/__init__.py:7-13) and a net assembled WITHOUT any explicit
+    device: masks, priors and parameters must meet on the GPU (drop-in behaviour of user scripts)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "NORMFLOW_AMD_KEEP_TORCH_DEFAULTS"}
+    for extra in (["--lat", "8,8", "--epochs", "4"], ["--lat", "4,4,8", "--kind", "rqs", "--layers", "2", "--epochs", "2", "--batch", "32"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "examples", "phi4_lattice.py")] + extra, env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "Sanity check is OK" in r.stdout
+        a, b = (float(t) for t in r.stdout.strip().splitlines()[-1].split())
+        assert a < 1e-8 and b < 1e-8
