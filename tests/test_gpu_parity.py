@@ -354,9 +354,13 @@ def test_edge_cases_empty_ragged_extreme():
     a2 = torch.ones(2, dtype=torch.uint8, device=DEV)
     y, lj = _hip.AffineCouplingFn.apply(x, p, None, a2, 0, False)
     assert rel(y, p[:, 0] + x * torch.exp(-p[:, 1].abs())) < 1e-6 and rel(lj, -p[:, 1].abs().sum(1)) < 1e-6
-    with pytest.raises(TypeError):
+    with pytest.raises(TypeError):                     # no bf16 kernels
+        _hip.RQSCouplingFn.apply(torch.zeros(1, 7, device=DEV, dtype=torch.bfloat16),
+                                 torch.zeros(1, 10, 7, device=DEV, dtype=torch.bfloat16), None, act, o, False)
+    with pytest.raises(_hip.NormflowHipError):         # fp16 storage exists for knots_len 4/8/16 only
+        o5 = _hip.make_rqs_opts(5, (-1, 1), (-1, 1), {'left': 'linear', 'right': 'linear'}, _hip.LAYOUT_FULL)
         _hip.RQSCouplingFn.apply(torch.zeros(1, 7, device=DEV, dtype=torch.float16),
-                                 torch.zeros(1, 10, 7, device=DEV, dtype=torch.float16), None, act, o, False)
+                                 torch.zeros(1, 13, 7, device=DEV, dtype=torch.float16), None, act, o5, False)
 
 
 # -------------------------------------------------- BASELINE sizes: size-independent properties
