@@ -45,6 +45,11 @@ struct RqsArgs {
 // ------------------------------------------------------------------ kernels
 // Unit -> (site, parameter column).  PAIR: unit h covers sites 2h, 2h+1 and the
 // active one is read from the mask; FULL: unit = site.
+template <typename S> __device__ __forceinline__ S ld_stream(const S *p) { return __builtin_nontemporal_load(p); }
+template <> __device__ __forceinline__ __half ld_stream<__half>(const __half *p) {
+  return __ushort_as_half(__builtin_nontemporal_load(reinterpret_cast<const unsigned short *>(p)));
+}
+
 // T = arithmetic type, S = storage type of x, params and y (S = T, or S = __half with T = float: BASELINE config 5,
 // "fp16 params / fp32 log-det accumulate" -- half the HBM bytes per site, log-det partials in double as always).
 template <typename T, typename S, int MT, int MODE, bool PAIR>
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(kBlock) void rqs_kernel(RqsArgs A) {
       if constexpr (MT > 0) {
         RegCol<T, C> a;
 #pragma unroll
-        for (int c = 0; c < C; ++c) a[c] = T(par[int64_t(c) * A.Vp + u]);
+        for (int c = 0; c < C; ++c) a[c] = T(ld_stream(&par[int64_t(c) * A.Vp + u]));   // logits are read once: nontemporal (+8 % on the same box)
         rqs_site<T, MT, MODE == kInv>(a, A.P, v, val, logd);
       } else {
         LdsCol<T> a{reinterpret_cast<T *>(smem_raw) + threadIdx.x, int(blockDim.x)};
