@@ -230,3 +230,50 @@ def test_spectral_block_host_side(golden):
     want = [math.log(0.7) + math.log(0.5), math.log(1.3 * k2max) - math.log(0.5)]
     assert np.allclose(f.ipsd_net.logy.detach().double().numpy(), want, atol=1e-6)
     assert f.ipsd_net.knots_len == 2 and f.ipsd_net.smooth
+
+
+def test_conv_weight_layout_planning_and_packers():
+    """nf_conv_weight_layout is pure planning (no GPU): which layers get the persistent kernel's row-packed
+    weights, and that the host packers produce that layout -- checked element by element against the
+    definition in include/normflow_hip.h."""
+    import ctypes as C
+    lib = _hip.load()
+
+    def layout(lat, ks, cin, cout, compact, fused, dtype=0):
+        d = len(lat)
+        lat4 = (C.c_int32 * 4)(*([1] * (4 - d) + list(lat)))
+        k4 = (C.c_int32 * 4)(*([1] * (4 - d) + list(ks)))
+        return lib.nf_conv_weight_layout(lat4, k4, cin, cout, int(compact), int(fused), dtype), lat4, k4
+
+    assert layout((32,) * 4, (3,) * 4, 8, 46, True, True)[0] == 1          # fused last layer of the bench
+    assert layout((32,) * 4, (3,) * 4, 8, 8, False, False)[0] == 1         # 8 -> 8 layer
+    assert layout((32,) * 4, (3,) * 4, 1, 8, False, False)[0] == 0         # first layer: K-packed fragments
+    assert layout((32,) * 4, (3,) * 4, 8, 46, True, False, dtype=1)[0] == 0  # fp64: one-box kernel
+    assert layout((32,) * 4, (3, 3, 3, 5), 8, 8, False, False)[0] == 0     # k3 != 3
+    assert layout((32,) * 4, (3,) * 4, 6, 8, False, False)[0] == 0         # cin % 4 != 0
+    assert layout((48,) * 4, (3,) * 4, 8, 46, True, True)[0] == 1          # not a power of two: still the persistent kernel
+    assert lib.nf_conv_weight_layout(None, None, 8, 8, 0, 0, 0) == -1
+
+    torch.manual_seed(0)
+    for cout, compact, fused in ((46, True, True), (8, False, False), (20, True, False)):
+        cin, ks, lat = 8, (3, 3, 3, 3), (8, 8, 8, 16)
+        w = torch.randn((cout, cin) + ks, dtype=torch.float32, device=CPU)
+        code, lat4, k4 = layout(lat, ks, cin, cout, compact, fused)
+        assert code == 1
+        if lib.nf_conv_two_site(cout, int(compact), lat[-1], ks[-1]) and not fused:
+            w2 = w.new_zeros((16, cin) + ks[:-1] + (ks[-1] + 1,))
+            w2[:cout, ..., :ks[-1]] = w
+            w2[8:8 + cout, ..., 1:] = w
+            w = w2
+        p = _hip.conv_weight_for_layer(w, lat4, k4, cin, cout, compact, fused, 0)
+        k3, nt = w.shape[-1], (w.shape[0] + 15) // 16
+        rows = 27
+        assert tuple(p.shape) == (rows, cin // 4, 64, (k3 * nt + 3) // 4 * 4)
+        wf = w.reshape(w.shape[0], cin, rows, k3)
+        g = torch.Generator().manual_seed(1)
+        for _ in range(400):
+            row, kq, lane, j3, t = (int(torch.randint(0, n, (1,), generator=g)) for n in (rows, cin // 4, 64, k3, nt))
+            col, ci = t * 16 + (lane & 15), kq * 4 + (lane >> 4)
+            want = float(wf[col, ci, row, j3]) if col < w.shape[0] else 0.0
+            assert float(p[row, kq, lane, j3 * nt + t]) == want
+        assert float(p[..., k3 * nt:].abs().sum()) == 0.0
