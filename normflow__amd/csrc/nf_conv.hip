@@ -514,7 +514,7 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
   static const int mt_first = getenv("NF_CONV_MT") ? atoi(getenv("NF_CONV_MT")) : 4;
   // layers the persistent kernel (nf_conv_pipe.hip) can take are planned with its MT = 2 boxes straight away
   static const int pipe_off = getenv("NF_CONV_PIPE") ? (atoi(getenv("NF_CONV_PIPE")) == 0) : 0;
-  const bool pipe_candidate = sizeof(T) == 4 && !pipe_off && !A.packed && (cin & 3) == 0 && A.k[3] == 3 &&
+  const bool pipe_candidate = sizeof(T) == 4 && !pipe_off && !A.packed && A.k[3] == 3 &&
                               A.k[0] * A.k[1] * A.k[2] >= 2 && A.nt_total <= 3 && !(A.dbg & 15);
   int MT = (mt_first == 2 || pipe_candidate) ? 2 : 4;
   int box[4];

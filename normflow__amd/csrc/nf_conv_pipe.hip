@@ -108,6 +108,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_pipe_kernel(ConvArgs A) {
   //    offsets of group l and issue() fetches them with v_readlane.
   // Row offsets in the input are recomputed only when the next phase belongs to a new box.
   const T *__restrict__ nsrc = nullptr;
+  int nreal = 4;                                            // real channels in the next phase's quad (cin is zero-padded to a multiple of 4)
   T *nbuf = buf;
   constexpr int kG = WIDE ? 1 : kGPI;                       // groups per MFMA-loop iteration
   // narrow state
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_pipe_kernel(ConvArgs A) {
     if constexpr (WIDE) {
       so = i >> 2;
       sc = i & 3;
-      svw = *reinterpret_cast<const f32x4 *>(nsrc + int64_t(sc) * A.V + pick(woff, so));
+      svw = *reinterpret_cast<const f32x4 *>(nsrc + int64_t(sc < nreal ? sc : 0) * A.V + pick(woff, so));
     } else {
 #pragma unroll
       for (int j = 0; j < kGPI; ++j) {
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_pipe_kernel(ConvArgs A) {
         const int off = __builtin_amdgcn_readlane(myoff, gi) + nx3;
         const int drow = __builtin_amdgcn_readlane(mydst, gi);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) sv[j][c] = nsrc[int64_t(c) * A.V + off];
+        for (int c = 0; c < 4; ++c) sv[j][c] = nsrc[int64_t(c < nreal ? c : 0) * A.V + off];
         sdst[j] = (drow >= 0 && lane < h3) ? drow + lane : A.S - kSlack + lane;
       }
     }
@@ -163,17 +164,19 @@ __global__ __launch_bounds__(kBlock, 2) void conv_pipe_kernel(ConvArgs A) {
     if constexpr (WIDE) {
       T *pl = nbuf + sc * A.S;
       const int d = pick(wdst, so);
-      pl[d] = svw[0]; pl[d + 1] = svw[1]; pl[d + 2] = svw[2]; pl[d + 3] = svw[3];
-      pl[pick(whalo, so)] = wk == 0 ? svw[0] : svw[3];
+      const f32x4 v = sc < nreal ? svw : f32x4{0.f, 0.f, 0.f, 0.f};     // padded channel planes are zero (selected HERE:
+      pl[d] = v[0]; pl[d + 1] = v[1]; pl[d + 2] = v[2]; pl[d + 3] = v[3];  //  touching svw at issue time would wait for the load)
+      pl[pick(whalo, so)] = wk == 0 ? v[0] : v[3];
     } else {
 #pragma unroll
       for (int j = 0; j < kGPI; ++j)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) nbuf[c * A.S + sdst[j]] = sv[j][c];
+        for (int c = 0; c < 4; ++c) nbuf[c * A.S + sdst[j]] = c < nreal ? sv[j][c] : 0.f;
     }
   };
   auto set_next = [&](int b, const int (&o)[4], int q, T *dstbuf, bool new_box) {
     nsrc = static_cast<const T *>(A.in) + (int64_t(b) * A.cin + 4 * q) * A.V;
+    nreal = A.cin - 4 * q < 4 ? A.cin - 4 * q : 4;
     nbuf = dstbuf;
     if (new_box) {
       if constexpr (WIDE) {
@@ -331,7 +334,9 @@ __global__ __launch_bounds__(kBlock, 2) void conv_pipe_kernel(ConvArgs A) {
 #pragma unroll
     for (int t = 0; t < 13; ++t) {
       request(a1, b1, 2 * t + 1);
-      if (t < 8) sh[t] = *reinterpret_cast<const f32x4 *>(nsrc + int64_t(t & 3) * A.V + woff[t >> 2]);
+      if (t < 8) {
+        sh[t] = *reinterpret_cast<const f32x4 *>(nsrc + int64_t((t & 3) < nreal ? (t & 3) : 0) * A.V + woff[t >> 2]);
+      }
       __builtin_amdgcn_sched_barrier(0);
       multiply(a0, b0);
       __builtin_amdgcn_sched_barrier(0);
@@ -344,8 +349,9 @@ __global__ __launch_bounds__(kBlock, 2) void conv_pipe_kernel(ConvArgs A) {
         const int g8 = t - kLag;
         T *pl = nbuf + (g8 & 3) * A.S;
         const int d = wdst[g8 >> 2];
-        pl[d] = sh[g8][0]; pl[d + 1] = sh[g8][1]; pl[d + 2] = sh[g8][2]; pl[d + 3] = sh[g8][3];
-        pl[whalo[g8 >> 2]] = wk == 0 ? sh[g8][0] : sh[g8][3];
+        const f32x4 v = (g8 & 3) < nreal ? sh[g8] : f32x4{0.f, 0.f, 0.f, 0.f};
+        pl[d] = v[0]; pl[d + 1] = v[1]; pl[d + 2] = v[2]; pl[d + 3] = v[3];
+        pl[whalo[g8 >> 2]] = wk == 0 ? v[0] : v[3];
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -435,7 +441,7 @@ int launch_conv_pipe(const ConvArgs &A0, int64_t B, int64_t nboxes, int fuse, hi
   static const int off = getenv("NF_CONV_PIPE") ? (atoi(getenv("NF_CONV_PIPE")) == 0) : 0;
   if (off) return 0;
   ConvArgs A = A0;
-  if (A.packed || (A.cin & 3) || A.k[3] != 3 || (A.dbg & 15) || A.stamps) return 0;
+  if (A.packed || A.k[3] != 3 || (A.dbg & 15) || A.stamps) return 0;    // cin % 4 != 0 (>= 8): channel planes zero-padded in LDS
   A.wide_no = 0; A.wide_llpr = 0;
   {
     static const int wide_off = getenv("NF_CONV_PIPE_NARROW") ? 1 : 0;     // A/B knob
