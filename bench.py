@@ -116,7 +116,7 @@ def time_fused_last_layer(cpl, lattice, m, dev, reps, batch):
     x = torch.randn(slab, V, device=dev, dtype=torch.float32, generator=g)
     opts = _hip.make_rqs_opts(m, (-5.0, 5.0), (-5.0, 5.0), {'left': 'linear', 'right': 'linear'}, _hip.LAYOUT_PAIR)
     w, b = last.weight.detach(), last.bias.detach()
-    f = lambda: _hip.conv_rqs(h, w, b, x, None, 0, opts, False)
+    f = lambda: _hip.conv_rqs(h, w, b, x, None, 0, opts, False, unit_input=True)    # h = tanh(...): the pipeline's own call
     for _ in range(2):
         f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

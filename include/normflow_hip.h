@@ -204,8 +204,13 @@ int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, void *out, 
  *       up to a multiple of 4 (zero fill).  I.e. fragment order permuted so that everything a lane needs for one
  *       kernel row sits in NV/4 16-byte words.  Used by the persistent kernel (fp32, cin % 4 == 0, k3 == 3,
  *       <= 48 output columns).
+ *   NF_WLAYOUT_SPLIT16  (2): fp16 pairs for the split-fp16 kernel, [column tile (3)][K slice (41)][hi|lo][64 lanes][4]:
+ *       lane = 16*g + n holds, for column 16*tile + n, the 4 input channels 4*(g&1)..+3 of tap (g>>1) of the slice;
+ *       slice s < 27: taps j3 = 0, 1 of kernel row s = (j0, j1, j2) row-major; slice 27 + i: taps j3 = 2 of kernel rows
+ *       2i and 2i+1 (zero for the missing row 27); hi = fp16(w), lo = fp16(w - hi).
+ * `fused`: bit 0 = the layer is the fused last layer (nf_conv_rqs), bit 1 = NF_CONV_UNIT_INPUT will be passed.
  * Returns the code, or -1 for invalid arguments. */
-enum { NF_WLAYOUT_FRAGMENT = 0, NF_WLAYOUT_ROWPACK = 1 };
+enum { NF_WLAYOUT_FRAGMENT = 0, NF_WLAYOUT_ROWPACK = 1, NF_WLAYOUT_SPLIT16 = 2 };
 int nf_conv_weight_layout(const int32_t *lattice, const int32_t *ksize, int cin, int cout, int compact,
                           int fused, int dtype);
 /* Which kernel the calling thread's last nf_conv_fwd / nf_conv_rqs launched: 0 = one box per workgroup
@@ -222,12 +227,18 @@ int nf_conv_last_path(void);
  * the coordinate sum of the active sites), an even fastest axis, knots_len in {4, 8, 16}.
  *   in (B, cin, V) hidden activations; wfrag/bias as nf_conv_fwd with cout = 3m-2;
  *   x_active, y (B, V); log0, logj (B); inverse != 0 applies the inverse map.
+ *   flags: NF_CONV_UNIT_INPUT = the caller guarantees |in| <= 1 (hidden activations that are tanh / sigmoid
+ *   outputs): eligible layers (8 -> 46 channels, 3^4 kernel, 32-site fastest axis) then run the split-fp16 kernel
+ *   (nf_conv_h.hip): every fp32 product as three fp16 matrix-core products with fp32 accumulation, ~1.7x the
+ *   rounding error of an fp32 chain, well inside the 1e-5 budget; the weights must then be packed in
+ *   NF_WLAYOUT_SPLIT16 (nf_conv_weight_layout with `fused` = 1 | 2 says which layout a layer wants).
  */
+enum { NF_CONV_UNIT_INPUT = 1 };
 int nf_conv_rqs_supported(int cout, int m);
 int nf_conv_rqs(const void *in, const void *wfrag, const void *bias, const void *x_active,
                 const void *log0, void *y, void *logj, int64_t B, const int32_t *lattice,
                 const int32_t *ksize, int cin, int cout, int active_parity,
-                const nf_rqs_opts *opts, int inverse, void *workspace, size_t workspace_bytes,
+                const nf_rqs_opts *opts, int inverse, int flags, void *workspace, size_t workspace_bytes,
                 int dtype, void *stream);
 
 /* ---- end points of the flow ------------------------------------------------

@@ -65,7 +65,7 @@ PROTOTYPES = {
     "nf_conv_last_path": (_I, []),
     "nf_conv_weight_layout": (_I, [_P, _P, _I, _I, _I, _I, _I]),
     "nf_conv_rqs": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I,
-                         C.POINTER(RqsOpts), _I, _P, _SZ, _I, _P]),
+                         C.POINTER(RqsOpts), _I, _I, _P, _SZ, _I, _P]),
     "nf_conv_fwd": (_I, [_P, _P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I, _I, _I,
                          _I, _P]),
 }
@@ -418,6 +418,8 @@ def conv_weight_for_layer(w, lat4, k4, cin, cout, compact, fused, dtype_code):
         raise RuntimeError("nf_conv_weight_layout: invalid layer description")
     if code == 0:
         return frag
+    if code == 2:
+        return pack_conv_weight_split16(w)
     ntaps, kq, nt = frag.shape[:3]
     k3 = w.shape[-1]
     rows = ntaps // k3
@@ -426,6 +428,55 @@ def conv_weight_for_layer(w, lat4, k4, cin, cout, compact, fused, dtype_code):
     out = vals.new_zeros(rows, kq, 64, nv)
     out[..., :k3 * nt] = vals
     return out.contiguous()
+
+
+def pack_conv_weight_split16(w):
+    """(46, 8, 3, 3, 3, 3) fp32 weights -> NF_WLAYOUT_SPLIT16 (include/normflow_hip.h): fp16 hi / lo pairs in the
+    B-fragment order of v_mfma_f32_16x16x16_f16, [column tile][K slice][hi|lo][lane][4]."""
+    cout, cin = w.shape[:2]
+    assert cin == 8 and tuple(w.shape[2:]) == (3, 3, 3, 3) and cout <= 48
+    wp = w.new_zeros(48, 8, 27, 3)
+    wp[:cout] = w.reshape(cout, 8, 27, 3).float()
+    hi = wp.half()
+    lo = (wp - hi.float()).half()
+    dev = w.device
+    s = torch.arange(41, device=dev)
+    sel = torch.arange(2, device=dev)
+    row = torch.where(s[:, None] < 27, s[:, None].expand(41, 2), 2 * (s[:, None] - 27) + sel[None, :])      # (41, 2)
+    j3 = torch.where(s[:, None] < 27, sel[None, :].expand(41, 2), torch.full((41, 2), 2, device=dev))
+    valid = row < 27
+    row = row.clamp(max=26)
+    lane = torch.arange(64, device=dev)
+    n, g = lane & 15, lane >> 4
+    tile = torch.arange(3, device=dev)
+    co = (16 * tile[:, None] + n[None, :])                      # (3, 64)
+    ch = ((g & 1) * 4)[:, None] + torch.arange(4, device=dev)[None, :]      # (64, 4)
+    tapsel = g >> 1                                              # (64,)
+    out = torch.empty(3, 41, 2, 64, 4, dtype=torch.float16, device=dev)
+    for k, part in enumerate((hi, lo)):
+        # part[co, ch, row, j3] gathered to [tile, slice, lane, 4]
+        r_ = row[:, tapsel]                                      # (41, 64)
+        j_ = j3[:, tapsel]
+        v_ = valid[:, tapsel]
+        val = part[co[:, None, :, None], ch[None, None, :, :], r_[None, :, :, None], j_[None, :, :, None]]   # (3, 41, 64, 4)
+        out[:, :, k] = val * v_[None, :, :, None].to(val.dtype)
+    return out.contiguous()
+
+
+_UNIT_OK = {}
+
+
+def _weights_fit_fp16(w):
+    """finite and inside the fp16 range (the split-fp16 kernel's precondition on the weights); cached per
+    parameter version so that the device->host sync happens once per optimiser step, not per launch."""
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    ok = _UNIT_OK.get(key)
+    if ok is None:
+        if len(_UNIT_OK) > 256:
+            _UNIT_OK.clear()
+        ok = bool(torch.isfinite(w).all()) and float(w.abs().max()) < 6.0e4
+        _UNIT_OK[key] = ok
+    return ok
 
 
 def conv_supported(x, weight):
@@ -561,7 +612,7 @@ def conv_layer(x, weight, bias, act=0, compact=False, parity=0):
     return _conv_launch(x, weight.detach(), None if bias is None else bias.detach(), act, compact, parity)
 
 
-def conv_rqs(h, weight, bias, x_active, log0, parity, opts, inverse):
+def conv_rqs(h, weight, bias, x_active, log0, parity, opts, inverse, unit_input=False):
     """Fused last conv layer + RQ-spline coupling (nf_conv_rqs); inference only.
     h: (B, cin, *L) fp32 hidden activations; x_active: (B, V); returns (y (B, V), logJ (B))."""
     _require_device(h, weight, bias, x_active, log0)
@@ -573,7 +624,8 @@ def conv_rqs(h, weight, bias, x_active, log0, parity, opts, inverse):
     lat4 = (C.c_int32 * 4)(*([1] * (4 - d) + lat))
     k4 = (C.c_int32 * 4)(*([1] * (4 - d) + list(weight.shape[2:])))
     V = x_active.shape[1]
-    wfrag = conv_weight_for_layer(weight.detach(), lat4, k4, cin, weight.shape[0], True, True, NF_F32)
+    flags = 1 if (unit_input and _weights_fit_fp16(weight)) else 0          # NF_CONV_UNIT_INPUT: |h| <= 1 (tanh outputs)
+    wfrag = conv_weight_for_layer(weight.detach(), lat4, k4, cin, weight.shape[0], True, 1 | (flags << 1), NF_F32)
     bias = None if bias is None else bias.detach().contiguous()
     y = torch.empty_like(x_active)
     logj = torch.empty(B, dtype=x_active.dtype, device=x_active.device)
@@ -583,7 +635,7 @@ def conv_rqs(h, weight, bias, x_active, log0, parity, opts, inverse):
         l0 = log0[b0:b1] if log0 is not None else None
         _check(lib.nf_conv_rqs(_ptr(h[b0:b1]), _ptr(wfrag), _ptr(bias), _ptr(x_active[b0:b1]), _ptr(l0),
                                _ptr(y[b0:b1]), _ptr(logj[b0:b1]), b1 - b0, lat4, k4, cin, weight.shape[0],
-                               int(parity), C.byref(opts), int(inverse), _ptr(ws), ws.numel(), NF_F32,
+                               int(parity), C.byref(opts), int(inverse), flags, _ptr(ws), ws.numel(), NF_F32,
                                _stream()), "nf_conv_rqs")
     return y, logj
 

@@ -454,6 +454,7 @@ static thread_local int *g_dry_layout = nullptr;     // non-null: plan only (nf_
 extern "C" int nf_conv_last_path(void) { return g_last_path; }
 
 struct FuseInfo {           // non-null => the coupling epilogue replaces the store
+  int flags;                 // NF_CONV_UNIT_INPUT: |input| <= 1 guaranteed -> the split-fp16 kernel (nf_conv_h.hip) may run
   int mode;                 // 1 forward, 2 inverse
   const float *xact;
   float *yout;
@@ -515,7 +516,7 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
   // layers the persistent kernel (nf_conv_pipe.hip) can take are planned with its MT = 2 boxes straight away
   static const int pipe_off = getenv("NF_CONV_PIPE") ? (atoi(getenv("NF_CONV_PIPE")) == 0) : 0;
   const bool pipe_candidate = sizeof(T) == 4 && !pipe_off && !A.packed && A.k[3] == 3 &&
-                              A.k[0] * A.k[1] * A.k[2] >= 2 && A.nt_total <= 3 && !(A.dbg & 15);
+                              A.k[0] * A.k[1] * A.k[2] >= 2 && A.nt_total <= 3 && !(A.dbg & 15);   // (dbg bits >= 16 are timing ablations inside the persistent kernels)
   int MT = (mt_first == 2 || pipe_candidate) ? 2 : 4;
   int box[4];
   for (int attempt = 0; attempt < 2; ++attempt) {
@@ -608,6 +609,20 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
     *fz->blocks_out = nblocks;
   }
   g_last_path = 0;
+  if (fz && (fz->flags & NF_CONV_UNIT_INPUT)) {
+    if constexpr (sizeof(T) == 4) {
+      if (MT == 2) {     // split-fp16 products, weight-stationary (nf_conv_h.hip)
+        const int pr = launch_conv_h(A, B, nblocks, fuse, stream, g_dry_layout != nullptr);
+        if (pr == -2) { set_error("nf_conv_rqs: batch x boxes >= 2^31 work items, split the batch"); return NF_EINVAL; }
+        if (pr < 0) { set_error("nf_conv_rqs: could not launch the split-fp16 kernel"); return NF_ELAUNCH; }
+        if (pr == 1) {
+          if (g_dry_layout) { *g_dry_layout = NF_WLAYOUT_SPLIT16; return NF_OK; }
+          g_last_path = 3;
+          return check_launch("conv split-fp16 kernel");
+        }
+      }
+    }
+  }
   if (g_dry_layout) {                  // nf_conv_weight_layout: report which kernel (hence weight layout) this layer gets
     int pr = 0;
     if constexpr (sizeof(T) == 4) {
@@ -722,6 +737,8 @@ extern "C" int nf_conv_weight_layout(const int32_t *lattice, const int32_t *ksiz
   int64_t blocks = 0;
   FuseInfo fz{};
   fz.mode = 1;
+  fz.flags = (fused & 2) ? NF_CONV_UNIT_INPUT : 0;
+  fz.P.m = (cout + 2) / 3;                                  // knots_len of the fused spline (planning only)
   fz.partial = reinterpret_cast<double *>(uintptr_t(8));
   fz.partial_bytes = ~size_t(0);
   fz.blocks_out = &blocks;
@@ -740,7 +757,7 @@ extern "C" int nf_conv_rqs_supported(int cout, int m) {
 extern "C" int nf_conv_rqs(const void *in, const void *wfrag, const void *bias, const void *x_active,
                            const void *log0, void *y, void *logj, int64_t B, const int32_t *lattice,
                            const int32_t *ksize, int cin, int cout, int active_parity,
-                           const nf_rqs_opts *opts, int inverse, void *workspace, size_t workspace_bytes,
+                           const nf_rqs_opts *opts, int inverse, int flags, void *workspace, size_t workspace_bytes,
                            int dtype, void *stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   NF_REQUIRE(opts && x_active && y && logj && lattice, "nf_conv_rqs: NULL pointer");
@@ -752,6 +769,7 @@ extern "C" int nf_conv_rqs(const void *in, const void *wfrag, const void *bias, 
   int64_t blocks = 0;
   FuseInfo fz{};
   fz.mode = inverse ? 2 : 1;
+  fz.flags = flags;
   fz.xact = static_cast<const float *>(x_active);
   fz.yout = static_cast<float *>(y);
   fz.partial = static_cast<double *>(workspace);

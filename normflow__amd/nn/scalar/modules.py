@@ -115,7 +115,7 @@ class ConvAct(torch.nn.Sequential):
         return x
 
     def hidden_and_last(self, x):
-        """(hidden activations after all but the last conv, last conv module) when the stack
+        """(hidden activations after all but the last conv, last conv module, |hidden| <= 1?) when the stack
         maps onto the MFMA kernel and the last layer has no activation; else None.  Lets a
         coupling fuse the last layer with its own kernel."""
         if self.conv_kwargs.get('pre_act') is not None or x.dim() - 2 != self.conv_kwargs['conv_dim']:
@@ -125,7 +125,10 @@ class ConvAct(torch.nn.Sequential):
             return None
         for conv, act in plan[:-1]:
             x = _hip.conv_layer(x, conv.weight, conv.bias, act)
-        return x, plan[-1][0]
+        # |hidden| <= 1 when the last hidden activation is tanh or the logistic function: lets the fused kernel use
+        # split-fp16 products (nf_conv_h.hip)
+        unit = len(plan) > 1 and plan[-2][1] in (_hip.ACT_CODES['tanh'], _hip.ACT_CODES['expit'])
+        return x, plan[-1][0], unit
 
     def forward(self, x):
         out = self._run_fused(x) if self.conv_kwargs.get('pre_act') is None else None

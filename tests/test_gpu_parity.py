@@ -442,7 +442,9 @@ def _network_properties(shape, B, kinds, m=16):
     assert rel(xb, x) <= 2e-4 and float(lb.abs().max()) <= 2e-5 * max(1.0, float(lj.abs().max())) * 50
     assert torch.equal(yp, y[perm]) and torch.equal(ljp, lj[perm])
     y2, lj2 = net_(x[:1].clone().requires_grad_(True))        # differentiable path: logits materialised, K2 kernel
-    assert rel(y2, y[:1]) <= 5e-6 and rel(lj2, lj[:1]) <= 5e-6
+    # (the fused path may run split-fp16 products, the differentiable path runs fp32 ones: two roundings of the same
+    #  exact result, each within north_star's 1e-5 of the fp64 oracle -- see the per-kernel tests)
+    assert rel(y2, y[:1]) <= 1e-5 and rel(lj2, lj[:1]) <= 1e-5
 
 
 def test_config4_network_properties():
@@ -947,3 +949,46 @@ def test_example_script_runs_with_package_defaults():
         assert "Sanity check is OK" in r.stdout
         a, b = (float(t) for t in r.stdout.strip().splitlines()[-1].split())
         assert a < 1e-8 and b < 1e-8
+
+
+@pytest.mark.parametrize("shape,B", [((4, 2, 6, 32), 100), ((2, 2, 2, 32), 7), ((8, 8, 8, 32), 3)])
+def test_split_fp16_fused_last_layer(shape, B):
+    """nf_conv_h.hip: the fused last layer with every fp32 product as three fp16 matrix-core products (hidden
+    activations are tanh outputs, so |h| <= 1).  Against (a) the fp32 kernels run separately (conv + coupling) and
+    (b) the fp64 oracle, forward and inverse; several items per workgroup; asserts that this kernel ran.
+    Tolerances: north_star's 1e-5 relative on y and log|J| vs the oracle; 5e-6 vs the fp32 path (the split
+    products carry ~1.7x the rounding error of an fp32 chain)."""
+    torch.manual_seed(17)
+    m, C = 16, 46
+    net = ConvAct(1, C, 3, conv_dim=4, hidden_sizes=[8, 8], acts=['tanh', 'tanh', None]).to(DEV, torch.float32)
+    with torch.no_grad():
+        for p_ in list(net.parameters())[-2:]:
+            p_.mul_(0.3)
+    mask = EvenOddMask(shape=shape)
+    lim = dict(xlim=(-5.0, 5.0), ylim=(-5.0, 5.0), extrap={'left': 'linear', 'right': 'linear'})
+    cpl = RQSplineCoupling_([net, net], mask=mask, **lim).to(DEV)
+    x = 1.5 * torch.randn((B,) + shape, device=DEV, dtype=torch.float32)
+    for parity in (0, 1):
+        xa, xf = mask.purify(x, parity), mask.purify(x, 1 - parity)
+        l0 = torch.randn(B, device=DEV, dtype=torch.float32)
+        with torch.no_grad():
+            yf, lf = cpl._fused_atom(False, xa, xf, parity, net, l0)
+            assert _hip.load().nf_conv_last_path() == 3
+            params, lay = cpl._params(net, xf, parity)
+            opts = _hip.make_rqs_opts(m, lim["xlim"], lim["ylim"], lim["extrap"], lay)
+            act = mask.activity(parity).reshape(-1).to(DEV)
+            yu, lu = _hip.RQSCouplingFn.apply(xa.reshape(B, -1), params, l0, act, opts, False)
+            assert rel(yf.reshape(B, -1), yu) <= 5e-6 and rel(lf, lu) <= 5e-6
+            xb, lb = cpl._fused_atom(True, yf, xf, parity, net, lf)
+            assert _hip.load().nf_conv_last_path() == 3
+            assert rel(xb, xa) <= 5e-4 and rel(lb, l0) <= 5e-4
+            perm = torch.randperm(B, device=DEV)
+            yp, lp = cpl._fused_atom(False, xa[perm], xf[perm], parity, net, l0[perm])
+            assert torch.equal(yp, yf[perm]) and torch.equal(lp, lf[perm])          # deterministic, sample-independent
+        nb = min(B, 4)
+        convs = [mod for mod in net if hasattr(mod, 'weight')]
+        layers = [(c.weight.detach().double().cpu(), c.bias.detach().double().cpu()) for c in convs]
+        out = O.conv_act(xf[:nb].double().cpu().unsqueeze(1), layers, ['tanh', 'tanh', None])
+        yo, lo = O.rqs_coupling_atom(xa[:nb].double().cpu(), out, O.channel_mask(shape, parity),
+                                     log0=l0[:nb].double().cpu(), **lim)
+        assert rel(yf[:nb], yo) <= 1e-5 and rel(lf[:nb], lo) <= 1e-5
