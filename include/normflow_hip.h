@@ -193,6 +193,10 @@ int nf_conv_two_site(int cout, int compact, int l3, int k3);
 int nf_conv_cin_pad(int cin);
 int nf_conv_ntiles(int cout);
 int nf_conv_packed_steps(int cin, int ntaps);
+/* `compact`: 0 = (B, cout, V) planes; 1 = pair-compact (B, cout, V/2), active sites only; NF_OUT_SPLIT16 (2) = full
+ * lattice as fp16 (hi, lo) pairs, channel-last: (B, V, 16) halfs -- 8-output-channel two-site layers feeding
+ * nf_conv_rqs(flags = NF_CONV_UNIT_INPUT | NF_CONV_SPLIT16_INPUT); same bytes as the fp32 planes. */
+enum { NF_OUT_SPLIT16 = 2 };
 int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, void *out, int64_t B,
                 const int32_t *lattice, const int32_t *ksize, int cin, int cout, int act,
                 int compact, int active_parity, int dtype, void *stream);
@@ -204,10 +208,11 @@ int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, void *out, 
  *       up to a multiple of 4 (zero fill).  I.e. fragment order permuted so that everything a lane needs for one
  *       kernel row sits in NV/4 16-byte words.  Used by the persistent kernel (fp32, cin % 4 == 0, k3 == 3,
  *       <= 48 output columns).
- *   NF_WLAYOUT_SPLIT16  (2): fp16 pairs for the split-fp16 kernel, [column tile (3)][K slice (41)][hi|lo][64 lanes][4]:
- *       lane = 16*g + n holds, for column 16*tile + n, the 4 input channels 4*(g&1)..+3 of tap (g>>1) of the slice;
- *       slice s < 27: taps j3 = 0, 1 of kernel row s = (j0, j1, j2) row-major; slice 27 + i: taps j3 = 2 of kernel rows
- *       2i and 2i+1 (zero for the missing row 27); hi = fp16(w), lo = fp16(w - hi).
+ *   NF_WLAYOUT_SPLIT16  (2): fp16 pairs for the split-fp16 kernel, [column tile (3)][K slice (21)][hi|lo][64 lanes][8]:
+ *       slice 7*j3 + i = tap j3 (fastest axis) of kernel rows 4i..4i+3 ((j0, j1, j2) row-major; row 27 = zeros);
+ *       lane = 16*g + n holds, for column 16*tile + n, the 8 input channels of kernel row 4i + g;
+ *       hi = fp16(1024 w), lo = fp16(1024 w - hi) (the factor 2^10 keeps the lo parts of typical weights out of
+ *       fp16's subnormal range; the kernel scales the accumulators back).  Needs max|w| < 29.
  * `fused`: bit 0 = the layer is the fused last layer (nf_conv_rqs), bit 1 = NF_CONV_UNIT_INPUT will be passed.
  * Returns the code, or -1 for invalid arguments. */
 enum { NF_WLAYOUT_FRAGMENT = 0, NF_WLAYOUT_ROWPACK = 1, NF_WLAYOUT_SPLIT16 = 2 };
@@ -233,7 +238,9 @@ int nf_conv_last_path(void);
  *   rounding error of an fp32 chain, well inside the 1e-5 budget; the weights must then be packed in
  *   NF_WLAYOUT_SPLIT16 (nf_conv_weight_layout with `fused` = 1 | 2 says which layout a layer wants).
  */
-enum { NF_CONV_UNIT_INPUT = 1 };
+/*   NF_CONV_SPLIT16_INPUT (with NF_CONV_UNIT_INPUT): `in` is not (B, 8, V) fp32 but what the previous layer wrote
+ *   with nf_conv_fwd(compact = NF_OUT_SPLIT16): (B, V, 16) IEEE halfs = per site hi[8] | lo[8]. */
+enum { NF_CONV_UNIT_INPUT = 1, NF_CONV_SPLIT16_INPUT = 2 };
 int nf_conv_rqs_supported(int cout, int m);
 int nf_conv_rqs(const void *in, const void *wfrag, const void *bias, const void *x_active,
                 const void *log0, void *y, void *logj, int64_t B, const int32_t *lattice,

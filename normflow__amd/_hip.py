@@ -430,36 +430,28 @@ def conv_weight_for_layer(w, lat4, k4, cin, cout, compact, fused, dtype_code):
     return out.contiguous()
 
 
+# The weights are scaled by 2^10 before the split (the kernel scales the accumulators back, exactly): typical |w| ~ 0.1
+# would put the lo parts into fp16's subnormal range -- absolute resolution 6e-8, i.e. 5e-7 RELATIVE to w and, unlike
+# activation rounding, the same error at every site: it showed up as a coherent 1.7e-5 shift of log|J| on 32^4.
+SPLIT16_WEIGHT_SCALE = 1024.0
+
+
 def pack_conv_weight_split16(w):
     """(46, 8, 3, 3, 3, 3) fp32 weights -> NF_WLAYOUT_SPLIT16 (include/normflow_hip.h): fp16 hi / lo pairs in the
-    B-fragment order of v_mfma_f32_16x16x16_f16, [column tile][K slice][hi|lo][lane][4]."""
+    B-fragment order of v_mfma_f32_16x16x32_f16, [column tile (3)][K slice (21)][hi|lo][lane (64)][8]:
+    slice 7*j3 + i = tap j3 of kernel rows 4i..4i+3; lane 16*g + n holds the 8 input channels of row 4i+g for
+    column 16*tile + n (zero for row 27 and for columns >= cout)."""
     cout, cin = w.shape[:2]
     assert cin == 8 and tuple(w.shape[2:]) == (3, 3, 3, 3) and cout <= 48
-    wp = w.new_zeros(48, 8, 27, 3)
-    wp[:cout] = w.reshape(cout, 8, 27, 3).float()
+    wp = w.new_zeros(48, 8, 28, 3, dtype=torch.float32)
+    wp[:cout, :, :27] = w.reshape(cout, 8, 27, 3).float() * SPLIT16_WEIGHT_SCALE
     hi = wp.half()
     lo = (wp - hi.float()).half()
-    dev = w.device
-    s = torch.arange(41, device=dev)
-    sel = torch.arange(2, device=dev)
-    row = torch.where(s[:, None] < 27, s[:, None].expand(41, 2), 2 * (s[:, None] - 27) + sel[None, :])      # (41, 2)
-    j3 = torch.where(s[:, None] < 27, sel[None, :].expand(41, 2), torch.full((41, 2), 2, device=dev))
-    valid = row < 27
-    row = row.clamp(max=26)
-    lane = torch.arange(64, device=dev)
-    n, g = lane & 15, lane >> 4
-    tile = torch.arange(3, device=dev)
-    co = (16 * tile[:, None] + n[None, :])                      # (3, 64)
-    ch = ((g & 1) * 4)[:, None] + torch.arange(4, device=dev)[None, :]      # (64, 4)
-    tapsel = g >> 1                                              # (64,)
-    out = torch.empty(3, 41, 2, 64, 4, dtype=torch.float16, device=dev)
+    out = torch.empty(3, 21, 2, 64, 8, dtype=torch.float16, device=w.device)
     for k, part in enumerate((hi, lo)):
-        # part[co, ch, row, j3] gathered to [tile, slice, lane, 4]
-        r_ = row[:, tapsel]                                      # (41, 64)
-        j_ = j3[:, tapsel]
-        v_ = valid[:, tapsel]
-        val = part[co[:, None, :, None], ch[None, None, :, :], r_[None, :, :, None], j_[None, :, :, None]]   # (3, 41, 64, 4)
-        out[:, :, k] = val * v_[None, :, :, None].to(val.dtype)
+        # part[co = 16 t + n, ch, row = 4 i + g, j3]  ->  [t, j3, i, g, n, ch]
+        v = part.reshape(3, 16, 8, 7, 4, 3).permute(0, 5, 3, 4, 1, 2)       # t, j3, i, g, n, ch
+        out[:, :, k] = v.reshape(3, 21, 64, 8)
     return out.contiguous()
 
 
@@ -474,7 +466,7 @@ def _weights_fit_fp16(w):
     if ok is None:
         if len(_UNIT_OK) > 256:
             _UNIT_OK.clear()
-        ok = bool(torch.isfinite(w).all()) and float(w.abs().max()) < 6.0e4
+        ok = bool(torch.isfinite(w).all()) and float(w.abs().max()) * SPLIT16_WEIGHT_SCALE < 3.0e4
         _UNIT_OK[key] = ok
     return ok
 
@@ -494,19 +486,25 @@ def _conv_launch(x, weight, bias, act, compact, parity):
     d = len(lat)
     lat4 = (C.c_int32 * 4)(*([1] * (4 - d) + lat))
     k4 = (C.c_int32 * 4)(*([1] * (4 - d) + ksize))
-    if lib.nf_conv_two_site(cout, int(compact), lat[-1], ksize[-1]):
+    split16 = compact == 2                 # NF_OUT_SPLIT16: (B, V, 16) halfs, hi | lo per site
+    if split16 and not (lib.nf_conv_two_site(cout, 0, lat[-1], ksize[-1]) and cout == 8 and x.dtype == torch.float32):
+        raise NormflowHipError("split-fp16 output needs an fp32 two-site layer with 8 output channels")
+    if lib.nf_conv_two_site(cout, 0 if split16 else int(compact), lat[-1], ksize[-1]):
         # 16 columns: [0, cout) = the layer at site 2p (taps 0..k3-1), [8, 8+cout) = the same
         # channels at site 2p+1 (taps 1..k3): one extra tap along the fastest axis
         w2 = weight.new_zeros((16, cin) + tuple(ksize[:-1]) + (ksize[-1] + 1,))
         w2[:cout, ..., :ksize[-1]] = weight
         w2[8:8 + cout, ..., 1:] = weight
-        wfrag = conv_weight_for_layer(w2, lat4, k4, cin, cout, compact, False, _dtype_code(x))
+        wfrag = conv_weight_for_layer(w2, lat4, k4, cin, cout, False if split16 else compact, False, _dtype_code(x))
     else:
         wfrag = conv_weight_for_layer(weight, lat4, k4, cin, cout, compact, False, _dtype_code(x))
     V = 1
     for n in lat:
         V *= n
-    out = torch.empty((B, cout, V // 2) if compact else (B, cout) + tuple(lat), dtype=x.dtype, device=x.device)
+    if split16:
+        out = torch.empty((B, V, 16), dtype=torch.float16, device=x.device)
+    else:
+        out = torch.empty((B, cout, V // 2) if compact else (B, cout) + tuple(lat), dtype=x.dtype, device=x.device)
     for b0 in range(0, B, MAX_B):
         b1 = min(B, b0 + MAX_B)
         _check(lib.nf_conv_fwd(_ptr(x[b0:b1]), _ptr(wfrag), _ptr(bias), _ptr(out[b0:b1]), b1 - b0, lat4, k4,
@@ -612,20 +610,27 @@ def conv_layer(x, weight, bias, act=0, compact=False, parity=0):
     return _conv_launch(x, weight.detach(), None if bias is None else bias.detach(), act, compact, parity)
 
 
-def conv_rqs(h, weight, bias, x_active, log0, parity, opts, inverse, unit_input=False):
+def conv_rqs(h, weight, bias, x_active, log0, parity, opts, inverse, unit_input=False, lattice=None):
     """Fused last conv layer + RQ-spline coupling (nf_conv_rqs); inference only.
-    h: (B, cin, *L) fp32 hidden activations; x_active: (B, V); returns (y (B, V), logJ (B))."""
+    h: (B, cin, *L) fp32 hidden activations, or -- with `lattice` given -- the (B, V, 16) fp16 (hi, lo) pairs a
+    previous conv_layer(..., compact=2) wrote; x_active: (B, V); returns (y (B, V), logJ (B))."""
     _require_device(h, weight, bias, x_active, log0)
     lib = load()
     h, x_active = h.contiguous(), x_active.contiguous()
-    B, cin = h.shape[:2]
-    lat = list(h.shape[2:])
+    split_in = lattice is not None
+    B = h.shape[0]
+    cin = weight.shape[1] if split_in else h.shape[1]
+    lat = list(lattice) if split_in else list(h.shape[2:])
     d = len(lat)
     lat4 = (C.c_int32 * 4)(*([1] * (4 - d) + lat))
     k4 = (C.c_int32 * 4)(*([1] * (4 - d) + list(weight.shape[2:])))
     V = x_active.shape[1]
     flags = 1 if (unit_input and _weights_fit_fp16(weight)) else 0          # NF_CONV_UNIT_INPUT: |h| <= 1 (tanh outputs)
-    wfrag = conv_weight_for_layer(weight.detach(), lat4, k4, cin, weight.shape[0], True, 1 | (flags << 1), NF_F32)
+    if split_in:
+        if not flags or h.dtype != torch.float16 or tuple(h.shape) != (B, V, 16):
+            raise NormflowHipError("split-fp16 hidden activations need unit_input and a (B, V, 16) half tensor")
+        flags |= 2                                                           # NF_CONV_SPLIT16_INPUT
+    wfrag = conv_weight_for_layer(weight.detach(), lat4, k4, cin, weight.shape[0], True, 1 | ((flags & 1) << 1), NF_F32)
     bias = None if bias is None else bias.detach().contiguous()
     y = torch.empty_like(x_active)
     logj = torch.empty(B, dtype=x_active.dtype, device=x_active.device)

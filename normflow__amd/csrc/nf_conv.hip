@@ -480,6 +480,8 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
     A.k[mu] = ksize[mu];
     V *= lattice[mu];
   }
+  const int out_split16 = compact == 2 ? 1 : 0;     // NF_OUT_SPLIT16: full lattice, fp16 (hi, lo) pairs, channel-last
+  if (out_split16) compact = 0;
   if (compact) NF_REQUIRE(A.L[3] % 2 == 0, "nf_conv_fwd: pair-compact output needs an even fastest axis");
   if (B == 0 || V == 0) return NF_OK;
   A.in = in;
@@ -494,6 +496,10 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
   if (A.sh2) A.nt_total = 1;
   A.nt_total = (cout + 15) >> 4;
   A.act = act; A.compact = compact ? 1 : 0; A.parity = active_parity & 1;
+  A.out_split16 = out_split16;
+  if (out_split16)
+    NF_REQUIRE(sizeof(T) == 4 && cout == 8 && A.sh2 && A.L[3] % 4 == 0 && !fz,
+               "nf_conv_fwd: split-fp16 output needs fp32, 8 output channels and a fastest axis that is a multiple of 4");
   A.packed = (cin % 4) != 0 && cin < 8;   // larger odd channel counts: zero-pad to a multiple of 4 and chunk
   if (A.packed) {
     const int ktot = cin * ksize[0] * ksize[1] * ksize[2] * A.kt3;
@@ -609,9 +615,12 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
     *fz->blocks_out = nblocks;
   }
   g_last_path = 0;
+  if (fz && (fz->flags & NF_CONV_SPLIT16_INPUT))
+    NF_REQUIRE((fz->flags & NF_CONV_UNIT_INPUT) && sizeof(T) == 4 && MT == 2, "nf_conv_rqs: split-fp16 input without the split-fp16 kernel");
   if (fz && (fz->flags & NF_CONV_UNIT_INPUT)) {
     if constexpr (sizeof(T) == 4) {
       if (MT == 2) {     // split-fp16 products, weight-stationary (nf_conv_h.hip)
+        if (fz->flags & NF_CONV_SPLIT16_INPUT) A.dbg |= 0x10000;     // carried to the kernel in a spare bit
         const int pr = launch_conv_h(A, B, nblocks, fuse, stream, g_dry_layout != nullptr);
         if (pr == -2) { set_error("nf_conv_rqs: batch x boxes >= 2^31 work items, split the batch"); return NF_EINVAL; }
         if (pr < 0) { set_error("nf_conv_rqs: could not launch the split-fp16 kernel"); return NF_ELAUNCH; }
@@ -620,6 +629,7 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
           g_last_path = 3;
           return check_launch("conv split-fp16 kernel");
         }
+        NF_REQUIRE(!(fz->flags & NF_CONV_SPLIT16_INPUT), "nf_conv_rqs: split-fp16 input but the layer is not eligible for the split-fp16 kernel");
       }
     }
   }
@@ -632,7 +642,7 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
     return NF_OK;
   }
   if constexpr (sizeof(T) == 4) {
-    if (cin == 1 && A.sh2 && !fz) {     // first ConvAct layer: data-movement kernel (nf_conv_pipe.hip, K5c)
+    if (cin == 1 && A.sh2 && !fz && !A.out_split16) {     // first ConvAct layer: data-movement kernel (nf_conv_pipe.hip, K5c)
       const int pr = launch_conv_c1(A, MT, B, nblocks, stream);
       if (pr == -2) { set_error("nf_conv_fwd: batch x boxes >= 2^31 work items, split the batch"); return NF_EINVAL; }
       if (pr < 0) { set_error("nf_conv_fwd: could not launch the single-channel kernel"); return NF_ELAUNCH; }

@@ -1,6 +1,7 @@
 // nf_conv_core.h -- device code shared by the convolution kernels (nf_conv.hip: one box per
 // workgroup; nf_conv_pipe.hip: persistent workgroups with staging overlapped with the MFMAs).
 #pragma once
+#include <hip/hip_fp16.h>
 #include "nf_rqs_core.h"
 
 namespace nf {
@@ -53,6 +54,7 @@ struct ConvArgs {
   int dbg;              // profiling ablation (NF_CONV_DBG): bit0 skip staging, bit1 skip the MFMA loop
   int64_t nitems;       // nf_conv_pipe.hip: (sample, box) items in the launch, boxes per sample
   int nboxes;
+  int out_split16;          // two-site layers with 8 output channels: store (hi, lo) fp16 pairs, channel-last, 32 bytes per site
   int wide_no, wide_llpr;   // nf_conv_pipe.hip wide staging: row blocks per wave (0 = narrow), log2(lanes per row)
 };
 
@@ -236,6 +238,35 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, const int (&o)[
             tile[co * CS + zr * b3 + 2 * p3 + shift] = activate(acc[mt][0][r] + bv, A.act);
           }
         lds_barrier();
+        if (A.out_split16) {
+          // the consumer is the split-fp16 kernel (nf_conv_h.hip): hand it every site's 8 channels already split
+          // into fp16 (hi, lo) pairs, channel-last -- one conversion per site here instead of one per halo copy there
+          typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+          unsigned char *ob = reinterpret_cast<unsigned char *>(out_b);
+          for (int t = threadIdx.x; t < rows * b3; t += kBlock) {
+            int zr = t / b3;
+            const int x3 = o[3] + (t - zr * b3);
+            h8 hi, lo;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              const float v = tile[c * CS + t];
+              const _Float16 hh = static_cast<_Float16>(v);
+              hi[c] = hh;
+              lo[c] = static_cast<_Float16>(v - static_cast<float>(hh));
+            }
+            const int z2 = zr & (A.box[2] - 1);
+            zr >>= A.lbox[2];
+            const int z1 = zr & (A.box[1] - 1);
+            zr >>= A.lbox[1];
+            const int x0 = o[0] + zr, x1 = o[1] + z1, x2 = o[2] + z2;
+            if (x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2] && x3 < A.L[3]) {
+              unsigned char *d = ob + (((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + x3) * 32;
+              *reinterpret_cast<h8 *>(d) = hi;
+              *reinterpret_cast<h8 *>(d + 16) = lo;
+            }
+          }
+          return;
+        }
         const int lq = lb3 - 1;                                  // log2(16-byte pieces per row) = log2(b3 / 4)
         const int per_ch = rows << lq;
         for (int q = threadIdx.x; q < 8 * per_ch; q += kBlock) {

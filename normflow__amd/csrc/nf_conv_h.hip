@@ -27,23 +27,25 @@
 
 namespace nf {
 
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace h {
 constexpr int H0 = 4, H1 = 4, H2 = 4, H3 = 34;            // halo box of a 2x2x2x32 box under a 3^4 kernel
 constexpr int NSITE = H0 * H1 * H2 * H3;                  // 2176
 constexpr int NROW = H0 * H1 * H2;                        // 64 halo rows: one per lane of the loader wave
-constexpr int IMG = NSITE * 16;                           // bytes of one fp16 image (8 channels per site)
-// An image is four sub-images [channel quad q][parity pi of the halo index z3][row][17 entries of 8 bytes]: the 16 lanes of a
-// k-group of an A fragment read sites of ONE parity (active sites sit at stride 2) and ONE channel quad, i.e. 16
-// consecutive 8-byte entries = 128 contiguous bytes, all banks once.  (With 16 bytes per site in site order the same
-// read strides 32 bytes and is a 4-way bank conflict: measured 35 instead of ~18 cycles per MFMA.)
-constexpr int ROWB = 17 * 8;                              // bytes of a row in a sub-image
-constexpr int SUB = NROW * ROWB;                          // 8704 bytes
+constexpr int IMG = NSITE * 16;                           // bytes of one fp16 image (8 channels = 16 bytes per site)
+// An image is two sub-images [parity pi of the halo index z3][row][17 entries of 16 bytes]: the 16 lanes of a k-group of
+// an A fragment (v_mfma_f32_16x16x32_f16: k-group g = the 8 channels of ONE tap) read sites of one parity -- active
+// sites sit at stride 2 -- i.e. 16 consecutive entries = 256 contiguous bytes, no bank conflict.  (In plain site order
+// the same read strides 32 bytes: a 4-way conflict, measured 35 instead of ~18 cycles per MFMA.)
+constexpr int ROWB = 17 * 16;                             // bytes of a row in a sub-image
+constexpr int SUB = NROW * ROWB;                          // 17408 bytes
 __host__ __device__ constexpr int rowidx(int r) { return ((r / 9) * H1 + (r / 3) % 3) * H2 + r % 3; }   // kernel row -> halo row step
-constexpr int NS = 41;                                    // K slices: 27 (taps 0,1 of a kernel row) + 14 (third taps of two rows)
+// K slices of 32 = (4 kernel rows) x (8 channels) at ONE tap j3 of the fastest axis: slice sl = 7*j3 + i holds kernel
+// rows 4i .. 4i+3 (row 27 is padding: zero weights).  Same j3 for the four k-groups => same parity sub-image.
+constexpr int NS = 21;
 constexpr int UNITS = 128;                                // active sites per box
+constexpr float kInvWScale = 1.0f / 1024.0f;              // normflow__amd/_hip.py: SPLIT16_WEIGHT_SCALE
 constexpr int C = 46, M = 16;
 constexpr int PT = C * UNITS * 4;                         // bytes of the logit scratch
 constexpr int LDS_BYTES = 4 * IMG + PT;
@@ -78,8 +80,8 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
 
   if (wave < 3) {
     // ============================================================ compute waves: column tile `wave`
-    const f16x4 *__restrict__ wsp = static_cast<const f16x4 *>(A.wfrag) + (wave * NS * 2) * 64 + lane;
-    f16x4 bh[NS], bl[NS];
+    const f16x8 *__restrict__ wsp = static_cast<const f16x8 *>(A.wfrag) + (wave * NS * 2) * 64 + lane;
+    f16x8 bh[NS], bl[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       bh[s] = wsp[(2 * s) * 64];
@@ -87,22 +89,30 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     }
     const int co = (wave << 4) + (lane & 15);
     const float bv = (A.bias && co < A.cout) ? static_cast<const float *>(A.bias)[co] : 0.f;
-    // byte offsets of this lane's A reads inside an image, per site tile (= box row mt: z0 = mt>>2, z1 = (mt>>1)&1, z2 = mt&1).
-    // Box extents are even, so the parity of a row does not depend on the box.
-    int ta[8], tb[8];      // byte offsets in an image: ta for taps (0, 1) of a kernel row [tap = g>>1], tb for tap 2
+    // byte offset of this lane's A read = T[site tile][j3] + RG[i]: T places the lane's site (box row mt: z0 = mt>>2,
+    // z1 = (mt>>1)&1, z2 = mt&1; halo index 2p + parity + j3) in its parity sub-image, RG adds the halo rows of kernel row
+    // 4i + g.  Box extents are even, so the parity of a box row does not depend on the box.
+    int T[8][3], RG[7];
     {
-      const int q = g & 1, ts = g >> 1, p = lane & 15;
+      const int p = lane & 15;
 #pragma unroll
       for (int mt = 0; mt < 8; ++mt) {
         const int z0 = mt >> 2, z1 = (mt >> 1) & 1, z2 = mt & 1;
         const int par = (A.parity + z0 + z1 + z2) & 1;
         const int r0 = (z0 * H1 + z1) * H2 + z2;
-        const int za = 2 * p + par + ts;                  // halo index of tap ts
-        ta[mt] = (q * 2 + (za & 1)) * SUB + (r0 * 17 + (za >> 1)) * 8;
-        tb[mt] = (q * 2 + par) * SUB + (r0 * 17 + p + 1) * 8;       // tap 2: same parity as the site, one entry on
+#pragma unroll
+        for (int j3 = 0; j3 < 3; ++j3) {
+          const int z3 = 2 * p + par + j3;
+          T[mt][j3] = (z3 & 1) * SUB + (r0 * 17 + (z3 >> 1)) * 16;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int r = 4 * i + g;
+        const int rr = r < 27 ? r : 26;
+        RG[i] = (((rr / 9) * H1 + (rr / 3) % 3) * H2 + rr % 3) * ROWB;
       }
     }
-    const bool second = (g >> 1) != 0;
     lds_barrier();            // P: the mover has staged the first image
     for (int m = 0; m < n_my; ++m) {
       const unsigned char *imgH = smem_h + (m & 1) * 2 * IMG;
@@ -110,57 +120,38 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       f32x4 acc[8];
 #pragma unroll
       for (int mt = 0; mt < 8; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // 41 slices of 8 site tiles; the A fragments (hi, lo) of a slice are read TWO slices ahead into three named
-      // buffers (one wave per SIMD: nobody else hides the LDS latency), and the 24 MFMAs of a slice run hi*hi over
-      // the 8 tiles, then hi*lo, then lo*hi, so that an accumulator is touched every 8th MFMA only.
-      f16x4 ahA[8], alA[8], ahB[8], alB[8], ahC[8], alC[8];
-      auto fetch = [&](f16x4 (&ah)[8], f16x4 (&al)[8], int s) {
-        if (s < 27) {                       // taps 0 and 1 of kernel row s: the second tap is the next site
-          const int off = rowidx(s) * ROWB;
+      // 21 slices of 8 site tiles; A fragments (hi, lo: 16 + 16 bytes per lane and tile) are read one slice ahead; the 24
+      // MFMAs of a slice run hi*hi over the 8 tiles, then hi*lo, then lo*hi: an accumulator is touched every 8th MFMA.
+      f16x8 ahA[8], alA[8], ahB[8], alB[8];
+      auto fetch = [&](f16x8 (&ah)[8], f16x8 (&al)[8], int sl) {
+        const int j3 = sl / 7, i = sl % 7;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            ah[i] = *reinterpret_cast<const f16x4 *>(imgH + ta[i] + off);
-            al[i] = *reinterpret_cast<const f16x4 *>(imgL + ta[i] + off);
-          }
-        } else {                            // third taps of kernel rows 2i and 2i+1 (the last slice: row 26 and padding)
-          const int i2 = s - 27;
-          const int offA = rowidx(2 * i2) * ROWB;
-          const int offB = rowidx(2 * i2 + 1 < 27 ? 2 * i2 + 1 : 26) * ROWB;
-          const int sel = second ? offB : offA;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            ah[i] = *reinterpret_cast<const f16x4 *>(imgH + tb[i] + sel);
-            al[i] = *reinterpret_cast<const f16x4 *>(imgL + tb[i] + sel);
-          }
+        for (int t = 0; t < 8; ++t) {
+          const int a = T[t][j3] + RG[i];
+          ah[t] = *reinterpret_cast<const f16x8 *>(imgH + a);
+          al[t] = *reinterpret_cast<const f16x8 *>(imgL + a);
         }
       };
-      auto mult = [&](const f16x4 (&ah)[8], const f16x4 (&al)[8], int s) {
+      auto mult = [&](const f16x8 (&ah)[8], const f16x8 (&al)[8], int sl) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[i], bh[s], acc[i], 0, 0, 0);
+        for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[sl], acc[t], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[i], bl[s], acc[i], 0, 0, 0);
+        for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[sl], acc[t], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(al[i], bh[s], acc[i], 0, 0, 0);
+        for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[sl], acc[t], 0, 0, 0);
       };
       if (!(A.dbg & 256)) {     // dbg 256: timing ablation, no MFMA loop
         fetch(ahA, alA, 0);
-        fetch(ahB, alB, 1);
 #pragma unroll
-        for (int s3 = 0; s3 < NS; s3 += 3) {
-          if (s3 + 2 < NS) fetch(ahC, alC, s3 + 2);
+        for (int sl = 0; sl < NS; sl += 2) {
+          if (sl + 1 < NS) fetch(ahB, alB, sl + 1);
           __builtin_amdgcn_sched_barrier(0);
-          mult(ahA, alA, s3);
+          mult(ahA, alA, sl);
           __builtin_amdgcn_sched_barrier(0);
-          if (s3 + 1 < NS) {
-            if (s3 + 3 < NS) fetch(ahA, alA, s3 + 3);
+          if (sl + 1 < NS) {
+            if (sl + 2 < NS) fetch(ahA, alA, sl + 2);
             __builtin_amdgcn_sched_barrier(0);
-            mult(ahB, alB, s3 + 1);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          if (s3 + 2 < NS) {
-            if (s3 + 4 < NS) fetch(ahB, alB, s3 + 4);
-            __builtin_amdgcn_sched_barrier(0);
-            mult(ahC, alC, s3 + 2);
+            mult(ahB, alB, sl + 1);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -171,7 +162,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       for (int mt = 0; mt < 8; ++mt) {
         f32x4 v = acc[mt];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += bv;
+        for (int r = 0; r < 4; ++r) v[r] = v[r] * kInvWScale + bv;      // the weights were packed scaled by 2^10
         if (co < C) *reinterpret_cast<f32x4 *>(pt + co * UNITS + (mt << 4) + (g << 2)) = v;
       }
       lds_barrier();            // B2: logits complete
@@ -190,14 +181,53 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     x2 = x2 < 0 ? x2 + A.L[2] : (x2 >= A.L[2] ? x2 - A.L[2] : x2);
     return ((x0 * A.L[1] + x1) * A.L[2] + x2) * A.L[3];
   };
-  // Two halo rows per pass: lanes 0-31 take the 32 interior sites of row 2i, lanes 32-63 those of row 2i+1 (one 128-byte
-  // line per channel and row); the two halo sites of a row are copies of its own end sites (the box spans the axis).
-  constexpr int PB = 4;                          // passes per batch: 32 loads in flight per batch, two batches in flight
+  // Two halo rows per pass: lanes 0-31 take the 32 interior sites of row 2i, lanes 32-63 those of row 2i+1; the two halo
+  // sites of a row are copies of its own end sites (the box spans the axis).  Input either as 8 fp32 channel planes
+  // (split here: 8 loads and ~40 conversions per site and pass) or already split by the producing layer into
+  // channel-last fp16 pairs, 32 bytes per site (NF_CONV_SPLIT16_INPUT: two 16-byte loads, no arithmetic).
+  constexpr int PB = 4;                          // passes per batch, two batches in flight
   const int rs = lane >> 5, xs = lane & 31;
+  const bool pre = (A.dbg & 0x10000) != 0;       // input already split (flag carried in the high bits of dbg)
+  auto put = [&](unsigned char *imgH, int row, int z3, const f16x8 &hi, const f16x8 &lo) {
+    const int d = (z3 & 1) * SUB + (row * 17 + (z3 >> 1)) * 16;
+    *reinterpret_cast<f16x8 *>(imgH + d) = hi;
+    *reinterpret_cast<f16x8 *>(imgH + IMG + d) = lo;
+  };
+  auto put3 = [&](unsigned char *imgH, int row, const f16x8 &hi, const f16x8 &lo) {
+    put(imgH, row, xs + 1, hi, lo);
+    if (xs == 0) put(imgH, row, H3 - 1, hi, lo);            // periodic copies: site 0 -> right halo, site 31 -> left halo
+    if (xs == 31) put(imgH, row, 0, hi, lo);
+  };
   auto stage = [&](int b, const int (&o)[4], unsigned char *imgH) {
-    unsigned char *imgL = imgH + IMG;
-    const float *__restrict__ src = in + int64_t(b) * 8 * A.V + xs;
     const int myoff = row_offsets(o);
+    if (pre) {
+      const unsigned char *__restrict__ src = static_cast<const unsigned char *>(A.in) + (int64_t(b) * A.V + xs) * 32;
+      f16x8 h0[PB], l0[PB], h1[PB], l1[PB];
+      auto issue = [&](f16x8 (&h)[PB], f16x8 (&l)[PB], int p0) {
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+          const int oa = __builtin_amdgcn_readlane(myoff, 2 * (p0 + j));
+          const int ob = __builtin_amdgcn_readlane(myoff, 2 * (p0 + j) + 1);
+          const unsigned char *q = src + int64_t(rs ? ob : oa) * 32;
+          h[j] = *reinterpret_cast<const f16x8 *>(q);
+          l[j] = *reinterpret_cast<const f16x8 *>(q + 16);
+        }
+      };
+      auto commit = [&](const f16x8 (&h)[PB], const f16x8 (&l)[PB], int p0) {
+#pragma unroll
+        for (int j = 0; j < PB; ++j) put3(imgH, 2 * (p0 + j) + rs, h[j], l[j]);
+      };
+      issue(h0, l0, 0);
+#pragma unroll 1
+      for (int p0 = 0; p0 < NROW / 2; p0 += 2 * PB) {
+        issue(h1, l1, p0 + PB);
+        commit(h0, l0, p0);
+        if (p0 + 2 * PB < NROW / 2) issue(h0, l0, p0 + 2 * PB);
+        commit(h1, l1, p0 + PB);
+      }
+      return;
+    }
+    const float *__restrict__ src = in + int64_t(b) * 8 * A.V + xs;
     float v0[PB][8], v1[PB][8];
     auto issue = [&](float (&v)[PB][8], int p0) {
 #pragma unroll
@@ -219,19 +249,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
           hi[c] = hh;
           lo[c] = static_cast<_Float16>(v[j][c] - static_cast<float>(hh));
         }
-        const int row = 2 * (p0 + j) + rs;
-        const f16x4 h0 = {hi[0], hi[1], hi[2], hi[3]}, h1 = {hi[4], hi[5], hi[6], hi[7]};
-        const f16x4 l0 = {lo[0], lo[1], lo[2], lo[3]}, l1 = {lo[4], lo[5], lo[6], lo[7]};
-        auto put = [&](int z3) {                  // halo index z3 of this row <- the lane's site
-          const int d = (z3 & 1) * SUB + (row * 17 + (z3 >> 1)) * 8;
-          *reinterpret_cast<f16x4 *>(imgH + d) = h0;
-          *reinterpret_cast<f16x4 *>(imgH + d + 2 * SUB) = h1;
-          *reinterpret_cast<f16x4 *>(imgL + d) = l0;
-          *reinterpret_cast<f16x4 *>(imgL + d + 2 * SUB) = l1;
-        };
-        put(xs + 1);
-        if (xs == 0) put(H3 - 1);                 // periodic copies: site 0 -> right halo, site 31 -> left halo
-        if (xs == 31) put(0);
+        put3(imgH, 2 * (p0 + j) + rs, hi, lo);
       }
     };
     issue(v0, 0);
@@ -296,7 +314,7 @@ int launch_conv_h(const ConvArgs &A0, int64_t B, int64_t nboxes, int fuse, hipSt
   static const int off = getenv("NF_CONV_SPLIT16") ? (atoi(getenv("NF_CONV_SPLIT16")) == 0) : 0;
   if (off || !fuse) return 0;
   ConvArgs A = A0;
-  if (A.cin != 8 || A.cout != C || A.P.m != M || A.P.fx || A.P.fy || (A.dbg & 15) || A.stamps) return 0;
+  if (A.cin != 8 || A.cout != C || A.P.m != M || A.P.fx || A.P.fy || (A.dbg & 15) || A.stamps) return 0;   // (bit 0x10000 of dbg: input already split)
   for (int mu = 0; mu < 4; ++mu)
     if (A.k[mu] != 3) return 0;
   if (A.box[0] != 2 || A.box[1] != 2 || A.box[2] != 2 || A.box[3] != 32 || A.L[3] != 32) return 0;

@@ -235,10 +235,11 @@ class RQSplineCoupling_(Coupling_):
             got = net.hidden_and_last(self.preprocess_fz(x_frozen[b0:b1]))
             if got is None:
                 return None
-            h, last, unit = got
+            h, last, unit, split = got
             opts = _hip.make_rqs_opts((n_out + 2) // 3, self.xlim, self.ylim, self.extrap, _hip.LAYOUT_PAIR)
             val, lj = _hip.conv_rqs(h, last.weight, last.bias, v[b0:b1], None if l0 is None else l0[b0:b1], a,
-                                    opts, inverse, unit_input=unit)
+                                    opts, inverse, unit_input=unit,
+                                    lattice=tuple(x_frozen.shape[1:]) if split else None)
             vals.append(val)
             logs.append(lj)
         val = vals[0] if len(vals) == 1 else torch.cat(vals)

@@ -123,12 +123,33 @@ class ConvAct(torch.nn.Sequential):
         plan = self._plan()
         if plan is None or plan[-1][1] != 0 or not _hip.conv_supported(x, plan[0][0].weight):
             return None
-        for conv, act in plan[:-1]:
-            x = _hip.conv_layer(x, conv.weight, conv.bias, act)
         # |hidden| <= 1 when the last hidden activation is tanh or the logistic function: lets the fused kernel use
-        # split-fp16 products (nf_conv_h.hip)
+        # split-fp16 products (nf_conv_h.hip); when it will, the last hidden layer writes its output already split
+        # into fp16 (hi, lo) pairs, channel-last (one conversion per site instead of one per halo copy downstream)
         unit = len(plan) > 1 and plan[-2][1] in (_hip.ACT_CODES['tanh'], _hip.ACT_CODES['expit'])
-        return x, plan[-1][0], unit
+        split = unit and len(plan) > 2 and self._wants_split16(x, plan)
+        for n, (conv, act) in enumerate(plan[:-1]):
+            last_hidden = n == len(plan) - 2
+            x = _hip.conv_layer(x, conv.weight, conv.bias, act, compact=2 if (split and last_hidden) else False)
+        return x, plan[-1][0], unit, split
+
+    @staticmethod
+    def _wants_split16(x, plan):
+        import ctypes as C
+        last, prev = plan[-1][0], plan[-2][0]
+        lat = list(x.shape[2:])
+        d = len(lat)
+        if x.dtype != torch.float32 or prev.weight.shape[0] != 8 or prev.weight.shape[1] % 4 or d != 4:
+            return False
+        lib = _hip.load()
+        lat4 = (C.c_int32 * 4)(*lat)
+        k4 = (C.c_int32 * 4)(*list(last.weight.shape[2:]))
+        if not _hip._weights_fit_fp16(last.weight):
+            return False
+        if lib.nf_conv_weight_layout(lat4, k4, last.weight.shape[1], last.weight.shape[0], 1, 3, _hip.NF_F32) != 2:
+            return False
+        kp = list(prev.weight.shape[2:])
+        return bool(lib.nf_conv_two_site(8, 0, lat[-1], kp[-1])) and lat[-1] % 4 == 0
 
     def forward(self, x):
         out = self._run_fused(x) if self.conv_kwargs.get('pre_act') is None else None

@@ -444,7 +444,7 @@ def _network_properties(shape, B, kinds, m=16):
     y2, lj2 = net_(x[:1].clone().requires_grad_(True))        # differentiable path: logits materialised, K2 kernel
     # (the fused path may run split-fp16 products, the differentiable path runs fp32 ones: two roundings of the same
     #  exact result, each within north_star's 1e-5 of the fp64 oracle -- see the per-kernel tests)
-    assert rel(y2, y[:1]) <= 1e-5 and rel(lj2, lj[:1]) <= 1e-5
+    assert rel(y2, y[:1]) <= 5e-6 and rel(lj2, lj[:1]) <= 2e-6
 
 
 def test_config4_network_properties():
