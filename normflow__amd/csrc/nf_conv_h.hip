@@ -261,16 +261,26 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       commit(v1, p0 + PB);
     }
   };
+  auto pair_of = [&](int b, const int (&o)[4], int pass) {
+    const int u = pass * 64 + lane;
+    const int mt = u >> 4, p3 = u & 15;
+    const int x0 = o[0] + (mt >> 2), x1 = o[1] + ((mt >> 1) & 1), x2 = o[2] + (mt & 1);
+    return int64_t(b) * (A.V / 2) + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * (A.L[3] / 2) + p3;
+  };
+  float2 xpre[2] = {{0.f, 0.f}, {0.f, 0.f}};     // the x pairs of the item whose logits are (about to be) in pt
+  auto prefetch_x = [&](int b, const int (&o)[4]) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) xpre[pass] = reinterpret_cast<const float2 *>(A.xact)[pair_of(b, o, pass)];
+  };
   auto epilogue = [&](int b, const int (&o)[4], int64_t pidx) {
     double lacc = 0.0;
-#pragma unroll 1
+#pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       const int u = pass * 64 + lane;
-      const int mt = u >> 4, p3 = u & 15;
-      const int x0 = o[0] + (mt >> 2), x1 = o[1] + ((mt >> 1) & 1), x2 = o[2] + (mt & 1);
-      const int offp = (A.parity + x0 + x1 + x2) & 1;
-      const int64_t pair = int64_t(b) * (A.V / 2) + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * (A.L[3] / 2) + p3;
-      const float2 xv = reinterpret_cast<const float2 *>(A.xact)[pair];
+      const int mt = u >> 4;
+      const int offp = (A.parity + o[0] + (mt >> 2) + o[1] + ((mt >> 1) & 1) + o[2] + (mt & 1)) & 1;
+      const int64_t pair = pair_of(b, o, pass);
+      const float2 xv = xpre[pass];
       RegCol<float, C> a;
 #pragma unroll
       for (int c = 0; c < C; ++c) a[c] = pt[c * UNITS + u];
@@ -290,19 +300,49 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   int cb, co4[4];
   decode(vb, cb, co4);
   stage(cb, co4, smem_h);
+  // Pre-split input: the 64 16-byte loads of a whole item live in registers from one iteration to the next -- issued
+  // after item m+1 has been committed, committed after the epilogue of the following iteration -- so the copy never
+  // waits for memory.  (fp32 input keeps the in-iteration staging above: it is the fallback, not the pipeline's path.)
+  f16x8 qh[NROW / 2], ql[NROW / 2];
+  auto issue_item = [&](int b, const int (&o)[4]) {
+    const int myoff = row_offsets(o);
+    const unsigned char *__restrict__ src = static_cast<const unsigned char *>(A.in) + (int64_t(b) * A.V + xs) * 32;
+#pragma unroll
+    for (int i = 0; i < NROW / 2; ++i) {
+      const int oa = __builtin_amdgcn_readlane(myoff, 2 * i);
+      const int ob = __builtin_amdgcn_readlane(myoff, 2 * i + 1);
+      const unsigned char *q = src + int64_t(rs ? ob : oa) * 32;
+      qh[i] = *reinterpret_cast<const f16x8 *>(q);
+      ql[i] = *reinterpret_cast<const f16x8 *>(q + 16);
+    }
+  };
+  auto commit_item = [&](unsigned char *imgH) {
+#pragma unroll
+    for (int i = 0; i < NROW / 2; ++i) put3(imgH, 2 * i + rs, qh[i], ql[i]);
+  };
+  int n1b = cb, n1o[4] = {co4[0], co4[1], co4[2], co4[3]};      // item m + 1 (in registers when pre)
+  if (n_my > 1) decode(vb + nb, n1b, n1o);
+  if (pre && n_my > 1) issue_item(n1b, n1o);
+  prefetch_x(cb, co4);
   lds_barrier();                                // P: image 0 ready
   for (int m = 0; m < n_my; ++m) {
     if (m > 0 && !(A.dbg & 128)) epilogue(pb, po, int64_t(vb) + int64_t(m - 1) * nb);     // dbg 128: timing ablation
-    int nb_ = cb, no_[4] = {co4[0], co4[1], co4[2], co4[3]};
-    if (m + 1 < n_my) {
-      decode(vb + (m + 1) * nb, nb_, no_);
-      if (!(A.dbg & 64)) stage(nb_, no_, smem_h + ((m + 1) & 1) * 2 * IMG);                 // dbg 64: timing ablation
+    prefetch_x(cb, co4);                        // for the epilogue of item m, one iteration from now
+    if (m + 1 < n_my && !(A.dbg & 64)) {        // dbg 64: timing ablation
+      if (pre) commit_item(smem_h + ((m + 1) & 1) * 2 * IMG);
+      else stage(n1b, n1o, smem_h + ((m + 1) & 1) * 2 * IMG);
+    }
+    int n2b = n1b, n2o[4] = {n1o[0], n1o[1], n1o[2], n1o[3]};
+    if (m + 2 < n_my) {
+      decode(vb + (m + 2) * nb, n2b, n2o);
+      if (pre && !(A.dbg & 64)) issue_item(n2b, n2o);
     }
     lds_barrier();                              // B1
     pb = cb;
+    cb = n1b;
+    n1b = n2b;
 #pragma unroll
-    for (int mu = 0; mu < 4; ++mu) { po[mu] = co4[mu]; co4[mu] = no_[mu]; }
-    cb = nb_;
+    for (int mu = 0; mu < 4; ++mu) { po[mu] = co4[mu]; co4[mu] = n1o[mu]; n1o[mu] = n2o[mu]; }
     lds_barrier();                              // B2: logits of item m are in pt
   }
   epilogue(pb, po, int64_t(vb) + int64_t(n_my - 1) * nb);

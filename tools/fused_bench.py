@@ -13,7 +13,14 @@ x = torch.randn(slab, V, device=DEV, generator=g)
 w = 0.1 * torch.randn((46, 8, 3, 3, 3, 3), device=DEV, generator=g)
 b = 0.1 * torch.randn(46, device=DEV, generator=g)
 opts = _hip.make_rqs_opts(m, (-5.0, 5.0), (-5.0, 5.0), {'left': 'linear', 'right': 'linear'}, _hip.LAYOUT_PAIR)
-f = lambda: _hip.conv_rqs(h, w, b, x, None, 0, opts, False, unit_input=True)
+if os.environ.get("SPLITIN", "1") == "1":          # what the pipeline feeds the kernel: (B, V, 16) halfs, hi | lo per site
+    hp = h.reshape(slab, 8, V).permute(0, 2, 1).contiguous()
+    hi = hp.half()
+    h16 = torch.cat((hi, (hp - hi.float()).half()), dim=2).contiguous()
+    del hp, hi
+    f = lambda: _hip.conv_rqs(h16, w, b, x, None, 0, opts, False, unit_input=True, lattice=lat)
+else:
+    f = lambda: _hip.conv_rqs(h, w, b, x, None, 0, opts, False, unit_input=True)
 for _ in range(2): f()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
