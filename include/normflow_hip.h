@@ -218,6 +218,15 @@ int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, void *out, 
 enum { NF_WLAYOUT_FRAGMENT = 0, NF_WLAYOUT_ROWPACK = 1, NF_WLAYOUT_SPLIT16 = 2 };
 int nf_conv_weight_layout(const int32_t *lattice, const int32_t *ksize, int cin, int cout, int compact,
                           int fused, int dtype);
+/* A hidden 8 -> 8 layer whose input AND output are the fp16 (hi, lo) pair format (nf_conv_h.hip, conv_g_kernel: two-site
+ * columns, one v_mfma_f32_16x16x32_f16 slice per kernel row, three fp16 products per fp32 product).
+ *   in16, out16: (B, V, 16) halfs; wsplit: [kernel row (27)][hi|lo][64 lanes][8] halfs -- lane 16*g + n holds, for column
+ *   n = 8*shift + co, the 8 input channels of tap (g - shift) of that kernel row (zero outside 0..2), scaled by 2^10
+ *   and split as in NF_WLAYOUT_SPLIT16; bias (8) fp32 or NULL; act must keep |out| <= 1 (tanh, logistic).
+ *   nf_conv_split16_supported: 3^4 kernel, 8 -> 8 channels, 32-site fastest axis, even other extents. */
+int nf_conv_split16_supported(const int32_t *lattice, const int32_t *ksize, int cin, int cout, int act);
+int nf_conv_fwd_split16(const void *in16, const void *wsplit, const void *bias, void *out16, int64_t B,
+                        const int32_t *lattice, int act, void *stream);
 /* Which kernel the calling thread's last nf_conv_fwd / nf_conv_rqs launched: 0 = one box per workgroup
  * (nf_conv.hip), 1 = persistent workgroups with staging overlapped with the MFMAs (nf_conv_pipe.hip;
  * fp32, cin % 4 == 0, kernel extent 3 on the fastest axis), 2 = the single-input-channel kernel of the first

@@ -63,6 +63,8 @@ PROTOTYPES = {
     "nf_conv_wgrad": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I, _P]),
     "nf_conv_rqs_supported": (_I, [_I, _I]),
     "nf_conv_last_path": (_I, []),
+    "nf_conv_split16_supported": (_I, [_P, _P, _I, _I, _I]),
+    "nf_conv_fwd_split16": (_I, [_P, _P, _P, _P, _I64, _P, _I, _P]),
     "nf_conv_weight_layout": (_I, [_P, _P, _I, _I, _I, _I, _I]),
     "nf_conv_rqs": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I,
                          C.POINTER(RqsOpts), _I, _I, _P, _SZ, _I, _P]),
@@ -453,6 +455,37 @@ def pack_conv_weight_split16(w):
         v = part.reshape(3, 16, 8, 7, 4, 3).permute(0, 5, 3, 4, 1, 2)       # t, j3, i, g, n, ch
         out[:, :, k] = v.reshape(3, 21, 64, 8)
     return out.contiguous()
+
+
+def pack_conv_weight_split16_two_site(w):
+    """(8, 8, 3, 3, 3, 3) fp32 weights of a hidden layer -> the B fragments of conv_g_kernel (include/normflow_hip.h,
+    nf_conv_fwd_split16): [kernel row (27)][hi|lo][lane (64)][8]; lane 16*g + n: column n = 8*shift + co, tap g - shift."""
+    assert tuple(w.shape) == (8, 8, 3, 3, 3, 3)
+    wr = w.reshape(8, 8, 27, 3).float() * SPLIT16_WEIGHT_SCALE          # co, ch, row, j3
+    w2 = wr.new_zeros(16, 8, 27, 4)                                     # column, ch, row, tap g
+    w2[:8, :, :, :3] = wr
+    w2[8:, :, :, 1:] = wr
+    hi = w2.half()
+    lo = (w2 - hi.float()).half()
+    out = torch.empty(27, 2, 64, 8, dtype=torch.float16, device=w.device)
+    for k, part in enumerate((hi, lo)):
+        out[:, k] = part.permute(2, 3, 0, 1).reshape(27, 64, 8)         # row, (g, n), ch
+    return out.contiguous()
+
+
+def conv_layer_split16(h16, weight, bias, act, lattice):
+    """Hidden 8 -> 8 layer on fp16 (hi, lo) pairs in and out (nf_conv_fwd_split16); inference only."""
+    lib = load()
+    B = h16.shape[0]
+    lat4 = (C.c_int32 * 4)(*lattice)
+    wsp = pack_conv_weight_split16_two_site(weight.detach())
+    bias = None if bias is None else bias.detach().float().contiguous()
+    out = torch.empty_like(h16)
+    for b0 in range(0, B, MAX_B):
+        b1 = min(B, b0 + MAX_B)
+        _check(lib.nf_conv_fwd_split16(_ptr(h16[b0:b1]), _ptr(wsp), _ptr(bias), _ptr(out[b0:b1]), b1 - b0, lat4,
+                                       int(act), _stream()), "nf_conv_fwd_split16")
+    return out
 
 
 _UNIT_OK = {}

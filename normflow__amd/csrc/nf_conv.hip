@@ -642,7 +642,7 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
     return NF_OK;
   }
   if constexpr (sizeof(T) == 4) {
-    if (cin == 1 && A.sh2 && !fz && !A.out_split16) {     // first ConvAct layer: data-movement kernel (nf_conv_pipe.hip, K5c)
+    if (cin == 1 && A.sh2 && !fz) {     // first ConvAct layer: data-movement kernel (nf_conv_pipe.hip, K5c)
       const int pr = launch_conv_c1(A, MT, B, nblocks, stream);
       if (pr == -2) { set_error("nf_conv_fwd: batch x boxes >= 2^31 work items, split the batch"); return NF_EINVAL; }
       if (pr < 0) { set_error("nf_conv_fwd: could not launch the single-channel kernel"); return NF_ELAUNCH; }

@@ -385,4 +385,246 @@ int launch_conv_h(const ConvArgs &A0, int64_t B, int64_t nboxes, int fuse, hipSt
   return 1;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// K5g: a hidden 8 -> 8 ConvAct layer between two split-fp16 consumers.  Input and output are the channel-last fp16
+// (hi, lo) pairs, 32 bytes per site.  Two-site columns (column n = 8*shift + co = channel co at site 2p + shift) make
+// the four fastest-axis taps -1..+2 of a site pair the four k-groups of ONE v_mfma_f32_16x16x32_f16: a kernel row
+// (j0, j1, j2) is exactly one K slice (4 taps x 8 channels), 27 slices in all, A[pair p][k-group g] = the 8 channels of
+// halo site 2p + g -- parity g & 1, entry p + (g >> 1) of the parity-split image: conflict-free reads with immediate
+// offsets.  Every wave keeps all 27 B fragment pairs (216 registers) and owns two of the box's eight site tiles (a
+// tile = one box row of 16 pairs), i.e. 27 x 2 x 3 = 162 MFMAs per item where the fp32 kernel issues 432 four times
+// slower ones: the layer turns from MFMA-bound into data movement (32 B in, 32 B out per site), so the structure is the
+// first layer's (conv_c1_kernel): persistent workgroups, an item's input loads parked in registers for a whole
+// iteration, output through an LDS transpose.
+namespace h {
+constexpr int GS_CS = 256 + 8;                            // channel stride of the output transpose (floats)
+constexpr int G_LDS = 4 * IMG + 8 * GS_CS * 4;
+}
+
+__global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
+  using namespace h;
+  extern __shared__ __align__(16) unsigned char smem_g[];
+  float *ot = reinterpret_cast<float *>(smem_g + 4 * IMG);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4;
+  const int nb = gridDim.x;
+  const int vb = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
+  if (vb >= A.nitems) return;
+  const int n_my = int((A.nitems - vb + nb - 1) / nb);
+  auto decode = [&](int it, int &b, int (&o)[4]) {
+    b = it / A.nboxes;
+    int bid = it - b * A.nboxes;
+#pragma unroll
+    for (int mu = 3; mu >= 0; --mu) {
+      o[mu] = (bid % A.nbox[mu]) * A.box[mu];
+      bid /= A.nbox[mu];
+    }
+  };
+
+  // ---- weights: all 27 slices, hi and lo
+  const f16x8 *__restrict__ wsp = static_cast<const f16x8 *>(A.wfrag) + lane;
+  f16x8 bh[27], bl[27];
+#pragma unroll
+  for (int r = 0; r < 27; ++r) {
+    bh[r] = wsp[(2 * r) * 64];
+    bl[r] = wsp[(2 * r + 1) * 64];
+  }
+  const int col = lane & 15, co = col & 7, shift = col >> 3;
+  const float bv = (A.bias && co < A.cout) ? static_cast<const float *>(A.bias)[co] : 0.f;
+  // ---- A reads: tile = box row zr = 2*wave + mt; lane (pair p, tap g): parity g & 1, entry p + (g >> 1)
+  int T[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int zr = 2 * wave + mt;
+    const int r0 = ((zr >> 2) * H1 + ((zr >> 1) & 1)) * H2 + (zr & 1);
+    T[mt] = (g & 1) * SUB + (r0 * 17 + (lane & 15) + (g >> 1)) * 16;
+  }
+  // ---- staging: wave w copies halo rows 16w .. 16w+15, two per pass (lanes 0-31 / 32-63), one interior site per lane
+  const int rs = lane >> 5, xs = lane & 31;
+  auto row_offset = [&](const int (&o)[4], int row) {       // offset (sites) of halo row `row` in the input
+    const int z0 = row / (H1 * H2), z1 = (row / H2) % H1, z2 = row % H2;
+    int x0 = o[0] + z0 - 1, x1 = o[1] + z1 - 1, x2 = o[2] + z2 - 1;
+    x0 = x0 < 0 ? x0 + A.L[0] : (x0 >= A.L[0] ? x0 - A.L[0] : x0);
+    x1 = x1 < 0 ? x1 + A.L[1] : (x1 >= A.L[1] ? x1 - A.L[1] : x1);
+    x2 = x2 < 0 ? x2 + A.L[2] : (x2 >= A.L[2] ? x2 - A.L[2] : x2);
+    return ((x0 * A.L[1] + x1) * A.L[2] + x2) * A.L[3];
+  };
+  f16x8 qh[8], ql[8];
+  auto issue_item = [&](int b, const int (&o)[4]) {
+    const unsigned char *__restrict__ src = static_cast<const unsigned char *>(A.in) + (int64_t(b) * A.V + xs) * 32;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const unsigned char *q = src + int64_t(row_offset(o, 16 * wave + 2 * i + rs)) * 32;
+      qh[i] = *reinterpret_cast<const f16x8 *>(q);
+      ql[i] = *reinterpret_cast<const f16x8 *>(q + 16);
+    }
+  };
+  auto put = [&](unsigned char *imgH, int row, int z3, const f16x8 &hi, const f16x8 &lo) {
+    const int d = (z3 & 1) * SUB + (row * 17 + (z3 >> 1)) * 16;
+    *reinterpret_cast<f16x8 *>(imgH + d) = hi;
+    *reinterpret_cast<f16x8 *>(imgH + IMG + d) = lo;
+  };
+  auto commit_item = [&](unsigned char *imgH) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = 16 * wave + 2 * i + rs;
+      put(imgH, row, xs + 1, qh[i], ql[i]);
+      if (xs == 0) put(imgH, row, H3 - 1, qh[i], ql[i]);     // periodic copies of the row's end sites
+      if (xs == 31) put(imgH, row, 0, qh[i], ql[i]);
+    }
+  };
+
+  int cb, co4[4], n1b, n1o[4];
+  decode(vb, cb, co4);
+  issue_item(cb, co4);
+  commit_item(smem_g);
+  n1b = cb;
+#pragma unroll
+  for (int mu = 0; mu < 4; ++mu) n1o[mu] = co4[mu];
+  if (n_my > 1) {
+    decode(vb + nb, n1b, n1o);
+    issue_item(n1b, n1o);
+  }
+  lds_barrier();
+  for (int m = 0; m < n_my; ++m) {
+    const unsigned char *imgH = smem_g + (m & 1) * 2 * IMG;
+    const unsigned char *imgL = imgH + IMG;
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    // 27 slices, A fragments read two slices ahead (three named buffers)
+    f16x8 aA[2][2], aB[2][2], aC[2][2];            // [tile][hi|lo]
+    auto fetch = [&](f16x8 (&a)[2][2], int r) {
+      const int off = rowidx(r) * ROWB;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        a[mt][0] = *reinterpret_cast<const f16x8 *>(imgH + T[mt] + off);
+        a[mt][1] = *reinterpret_cast<const f16x8 *>(imgL + T[mt] + off);
+      }
+    };
+    auto mult = [&](const f16x8 (&a)[2][2], int r) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt][0], bh[r], acc[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt][0], bl[r], acc[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt][1], bh[r], acc[mt], 0, 0, 0);
+    };
+    fetch(aA, 0);
+    fetch(aB, 1);
+#pragma unroll
+    for (int r = 0; r < 27; r += 3) {
+      fetch(aC, r + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mult(aA, r);
+      __builtin_amdgcn_sched_barrier(0);
+      if (r + 3 < 27) fetch(aA, r + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mult(aB, r + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (r + 4 < 27) fetch(aB, r + 4);
+      __builtin_amdgcn_sched_barrier(0);
+      mult(aC, r + 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // bias + activation -> ot[co][box row][x3]: rows of D = pairs 4g + r of the tile
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int zr = 2 * wave + mt;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[mt][r] * kInvWScale + bv;
+        ot[co * GS_CS + zr * 32 + 2 * ((g << 2) + r) + shift] = A.act == kActTanh ? fast_tanh(v) : activate(v, A.act);
+      }
+    }
+    // the next item's image (loads issued one iteration ago), then the loads of the one after
+    if (m + 1 < n_my) commit_item(smem_g + ((m + 1) & 1) * 2 * IMG);
+    int n2b = n1b, n2o[4] = {n1o[0], n1o[1], n1o[2], n1o[3]};
+    if (m + 2 < n_my) {
+      decode(vb + (m + 2) * nb, n2b, n2o);
+      issue_item(n2b, n2o);
+    }
+    lds_barrier();                  // B1: ot complete, next image complete, this image consumed
+    {
+      // one site per thread: 8 channels -> fp16 (hi, lo) -> 32 bytes
+      const int t = threadIdx.x;
+      const int zr = t >> 5, x3 = t & 31;
+      f16x8 hi, lo;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float v = ot[c * GS_CS + t];
+        const _Float16 hh = static_cast<_Float16>(v);
+        hi[c] = hh;
+        lo[c] = static_cast<_Float16>(v - static_cast<float>(hh));
+      }
+      const int x0 = co4[0] + (zr >> 2), x1 = co4[1] + ((zr >> 1) & 1), x2 = co4[2] + (zr & 1);
+      unsigned char *d = static_cast<unsigned char *>(A.out) +
+                         (int64_t(cb) * A.V + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + x3) * 32;
+      *reinterpret_cast<f16x8 *>(d) = hi;
+      *reinterpret_cast<f16x8 *>(d + 16) = lo;
+    }
+    lds_barrier();                  // B2: ot free
+    cb = n1b;
+    n1b = n2b;
+#pragma unroll
+    for (int mu = 0; mu < 4; ++mu) { co4[mu] = n1o[mu]; n1o[mu] = n2o[mu]; }
+  }
+}
+
 }  // namespace nf
+
+using namespace nf;
+
+extern "C" int nf_conv_split16_supported(const int32_t *lattice, const int32_t *ksize, int cin, int cout, int act) {
+  using namespace nf::h;
+  static const int off = getenv("NF_CONV_SPLIT16") ? (atoi(getenv("NF_CONV_SPLIT16")) == 0) : 0;
+  if (off || !lattice || !ksize || cin != 8 || cout != 8) return 0;
+  if (act != kActTanh && act != kActSigmoid) return 0;                    // the OUTPUT must be fp16-safe as well
+  for (int mu = 0; mu < 4; ++mu)
+    if (ksize[mu] != 3) return 0;
+  if (lattice[3] != 32) return 0;
+  for (int mu = 0; mu < 3; ++mu)
+    if (lattice[mu] < 2 || (lattice[mu] & 1)) return 0;
+  return 1;
+}
+
+extern "C" int nf_conv_fwd_split16(const void *in16, const void *wsplit, const void *bias, void *out16, int64_t B,
+                                   const int32_t *lattice, int act, void *stream_) {
+  using namespace nf::h;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  NF_REQUIRE(in16 && wsplit && out16 && lattice, "nf_conv_fwd_split16: NULL pointer");
+  const int32_t k3[4] = {3, 3, 3, 3};
+  NF_REQUIRE(nf_conv_split16_supported(lattice, k3, 8, 8, act), "nf_conv_fwd_split16: layer not supported (needs a 32-site fastest axis, even other extents, tanh / sigmoid)");
+  NF_REQUIRE(B >= 0 && B <= 65535, "nf_conv_fwd_split16: batch outside [0, 65535]");
+  if (B == 0) return NF_OK;
+  ConvArgs A{};
+  A.in = in16; A.wfrag = wsplit; A.bias = bias; A.out = out16;
+  A.V = 1;
+  const int box[4] = {2, 2, 2, 32};
+  int64_t nboxes = 1;
+  for (int mu = 0; mu < 4; ++mu) {
+    A.L[mu] = lattice[mu]; A.k[mu] = 3; A.box[mu] = box[mu];
+    A.nbox[mu] = lattice[mu] / box[mu];
+    A.V *= lattice[mu];
+    nboxes *= A.nbox[mu];
+  }
+  A.cin = 8; A.cout = 8; A.act = act;
+  A.nitems = B * nboxes;
+  A.nboxes = int(nboxes);
+  NF_REQUIRE(A.nitems < (int64_t(1) << 31) - 4096, "nf_conv_fwd_split16: batch x boxes >= 2^31 work items, split the batch");
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipDeviceProp_t prop;
+    NF_REQUIRE(hipGetDeviceProperties(&prop, dev) == hipSuccess, "nf_conv_fwd_split16: no device properties");
+    ncu = prop.multiProcessorCount;
+  }
+  int64_t grid = ncu;
+  if (grid > A.nitems) grid = A.nitems;
+  grid = (grid + 7) & ~int64_t(7);
+  NF_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_g_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS) == hipSuccess,
+             "nf_conv_fwd_split16: cannot reserve %d B of LDS", G_LDS);
+  hipLaunchKernelGGL(conv_g_kernel, dim3(unsigned(grid)), dim3(256), G_LDS, stream, A);
+  return check_launch("conv split-fp16 two-site kernel");
+}

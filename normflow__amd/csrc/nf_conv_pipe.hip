@@ -719,7 +719,33 @@ __global__ __launch_bounds__(kBlock, 2) void conv_c1_kernel(ConvArgs A) {
       }
     commit_all(sh_commit, buf + ((m + 1) % 3) * A.S);        // item m + 1 (issued one item ago) -> its plane
     lds_barrier();                                         // ot complete; plane m + 1 complete
-    {
+    if (A.out_split16) {
+      // the next layer consumes fp16 (hi, lo) pairs, channel-last, 32 bytes per site (nf_conv_h.hip)
+      typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+      unsigned char *ob = static_cast<unsigned char *>(A.out) + int64_t(cb) * A.V * 32;
+      for (int t = threadIdx.x; t < 2 * UNITS; t += kBlock) {
+        int zr = t / b3;
+        const int x3 = co4[3] + (t - zr * b3);
+        h8 hi, lo;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float v = ot[c * CS + t];
+          const _Float16 hh = static_cast<_Float16>(v);
+          hi[c] = hh;
+          lo[c] = static_cast<_Float16>(v - static_cast<float>(hh));
+        }
+        const int z2 = zr & (A.box[2] - 1);
+        zr >>= A.lbox[2];
+        const int z1 = zr & (A.box[1] - 1);
+        zr >>= A.lbox[1];
+        const int x0 = co4[0] + zr, x1 = co4[1] + z1, x2 = co4[2] + z2;
+        if (x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2] && x3 < A.L[3]) {
+          unsigned char *d = ob + (((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + x3) * 32;
+          *reinterpret_cast<h8 *>(d) = hi;
+          *reinterpret_cast<h8 *>(d + 16) = lo;
+        }
+      }
+    } else {
       T *__restrict__ out_b = static_cast<T *>(A.out) + int64_t(cb) * A.cout * A.V;
       const int lq = lb3 - 1;
       const int lpc = (ilog2_c(UNITS) - lb3) + lq;          // log2(16-byte pieces per channel)
@@ -777,6 +803,7 @@ int launch_conv_c1(const ConvArgs &A0, int MT, int64_t B, int64_t nboxes, hipStr
   if (off) return 0;
   ConvArgs A = A0;
   if (A.cin != 1 || !A.sh2 || A.k[3] != 3 || (A.dbg & 15) || A.stamps || A.compact) return 0;
+  if (A.out_split16 && A.cout != 8) return 0;
   const int nrows = A.k[0] * A.k[1] * A.k[2];
   if (nrows != 27 && nrows != 9 && nrows != 3) return 0;
   const int L3 = A.L[3];

@@ -128,10 +128,37 @@ class ConvAct(torch.nn.Sequential):
         # into fp16 (hi, lo) pairs, channel-last (one conversion per site instead of one per halo copy downstream)
         unit = len(plan) > 1 and plan[-2][1] in (_hip.ACT_CODES['tanh'], _hip.ACT_CODES['expit'])
         split = unit and len(plan) > 2 and self._wants_split16(x, plan)
+        # when every hidden layer after the first is an 8 -> 8 layer the split-fp16 two-site kernel takes, the pairs
+        # are produced once by the first layer and flow through the whole stack
+        chain = split and self._split16_chain(x, plan)
+        lat = tuple(x.shape[2:])
         for n, (conv, act) in enumerate(plan[:-1]):
             last_hidden = n == len(plan) - 2
-            x = _hip.conv_layer(x, conv.weight, conv.bias, act, compact=2 if (split and last_hidden) else False)
+            if chain and n > 0:
+                x = _hip.conv_layer_split16(x, conv.weight, conv.bias, act, lat)
+            else:
+                x = _hip.conv_layer(x, conv.weight, conv.bias, act,
+                                    compact=2 if ((chain and n == 0) or (split and last_hidden)) else False)
         return x, plan[-1][0], unit, split
+
+    @staticmethod
+    def _split16_chain(x, plan):
+        import ctypes as C
+        lib = _hip.load()
+        lat = list(x.shape[2:])
+        lat4 = (C.c_int32 * 4)(*lat)
+        first, fact = plan[0]
+        if tuple(first.weight.shape[:2]) != (8, 1) or fact not in (_hip.ACT_CODES['tanh'], _hip.ACT_CODES['expit']):
+            return False
+        if not lib.nf_conv_two_site(8, 0, lat[-1], first.weight.shape[-1]):
+            return False
+        for conv, act in plan[1:-1]:
+            k4 = (C.c_int32 * 4)(*list(conv.weight.shape[2:]))
+            if conv.weight.dim() != 6 or not _hip._weights_fit_fp16(conv.weight):
+                return False
+            if not lib.nf_conv_split16_supported(lat4, k4, conv.weight.shape[1], conv.weight.shape[0], act):
+                return False
+        return True
 
     @staticmethod
     def _wants_split16(x, plan):

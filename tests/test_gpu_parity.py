@@ -992,3 +992,42 @@ def test_split_fp16_fused_last_layer(shape, B):
         yo, lo = O.rqs_coupling_atom(xa[:nb].double().cpu(), out, O.channel_mask(shape, parity),
                                      log0=l0[:nb].double().cpu(), **lim)
         assert rel(yf[:nb], yo) <= 1e-5 and rel(lf[:nb], lo) <= 1e-5
+
+
+def test_split_fp16_hidden_layer_and_chain():
+    """conv_g_kernel (8 -> 8 hidden layer on fp16 (hi, lo) pairs in and out) against the fp64 definition, and the whole
+    split chain of a ConvAct stack (first layer writes the pairs, hidden layer, fused last layer) against the fp32
+    kernels and the oracle."""
+    torch.manual_seed(23)
+    shape, B = (4, 2, 6, 32), 40
+    V = int(np.prod(shape))
+    g = torch.Generator(device='cpu').manual_seed(5)
+    h = torch.tanh(torch.randn((B, 8) + shape, generator=g, dtype=torch.float64, device='cpu'))
+    w = 0.2 * torch.randn((8, 8, 3, 3, 3, 3), generator=g, dtype=torch.float64, device='cpu')
+    b = 0.3 * torch.randn(8, generator=g, dtype=torch.float64, device='cpu')
+    ref = torch.tanh(O.circular_conv_fast(h, w, b))
+    hp = h.reshape(B, 8, V).permute(0, 2, 1).to(DEV, torch.float32).contiguous()
+    hi = hp.half()
+    h16 = torch.cat((hi, (hp - hi.float()).half()), dim=2).contiguous()
+    out16 = _hip.conv_layer_split16(h16, w.to(DEV, torch.float32), b.to(DEV, torch.float32), _hip.ACT_CODES['tanh'], shape)
+    out = (out16[..., :8].float() + out16[..., 8:].float()).permute(0, 2, 1).reshape((B, 8) + shape)
+    assert rel(out, ref) <= 1e-5        # (the fp32 kernels' bound for K = 648 terms is 1e-6 + 2e-7*0.3*648 = 4e-5)
+    # the chain through the package API
+    net = ConvAct(1, 46, 3, conv_dim=4, hidden_sizes=[8, 8], acts=['tanh', 'tanh', None]).to(DEV, torch.float32)
+    with torch.no_grad():
+        for p_ in list(net.parameters())[-2:]:
+            p_.mul_(0.3)
+    mask = EvenOddMask(shape=shape)
+    lim = dict(xlim=(-5.0, 5.0), ylim=(-5.0, 5.0), extrap={'left': 'linear', 'right': 'linear'})
+    cpl = RQSplineCoupling_([net, net], mask=mask, **lim).to(DEV)
+    x = 1.5 * torch.randn((B,) + shape, device=DEV, dtype=torch.float32)
+    xf = mask.purify(x, 1)
+    with torch.no_grad():
+        got = net.hidden_and_last(xf.unsqueeze(1))
+    assert got[3] and got[0].dtype == torch.float16 and tuple(got[0].shape) == (B, V, 16)
+    with torch.no_grad():
+        y, lj = cpl(x)
+        xb, lb = cpl.backward(y, lj)
+    y2, lj2 = cpl(x[:3].clone().requires_grad_(True))          # fp32 kernels, logits materialised
+    assert rel(y2, y[:3]) <= 5e-6 and rel(lj2, lj[:3]) <= 5e-6
+    assert rel(xb, x) <= 5e-4 and float(lb.abs().max()) <= 5e-4 * max(1.0, float(lj.abs().max()))
