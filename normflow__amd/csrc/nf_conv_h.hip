@@ -78,6 +78,26 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     }
   };
 
+  // the block's items are nb apart: (sample, box coordinates) advance by mixed-radix counters, no divisions
+  int sb_, sc_[4];
+  {
+    int so_[4];
+    decode(nb, sb_, so_);
+#pragma unroll
+    for (int mu = 0; mu < 4; ++mu) sc_[mu] = so_[mu];
+  }
+  auto advance = [&](int &b, int (&o)[4]) {
+    int carry = 0;
+#pragma unroll
+    for (int mu = 3; mu >= 0; --mu) {
+      o[mu] += sc_[mu] + carry * A.box[mu];
+      const int lim = A.nbox[mu] * A.box[mu];
+      carry = o[mu] >= lim ? 1 : 0;
+      o[mu] -= carry ? lim : 0;
+    }
+    b += sb_ + carry;
+  };
+
   if (wave < 3) {
     // ============================================================ compute waves: column tile `wave`
     const f16x8 *__restrict__ wsp = static_cast<const f16x8 *>(A.wfrag) + (wave * NS * 2) * 64 + lane;
@@ -321,7 +341,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     for (int i = 0; i < NROW / 2; ++i) put3(imgH, 2 * i + rs, qh[i], ql[i]);
   };
   int n1b = cb, n1o[4] = {co4[0], co4[1], co4[2], co4[3]};      // item m + 1 (in registers when pre)
-  if (n_my > 1) decode(vb + nb, n1b, n1o);
+  if (n_my > 1) advance(n1b, n1o);
   if (pre && n_my > 1) issue_item(n1b, n1o);
   prefetch_x(cb, co4);
   lds_barrier();                                // P: image 0 ready
@@ -334,7 +354,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     }
     int n2b = n1b, n2o[4] = {n1o[0], n1o[1], n1o[2], n1o[3]};
     if (m + 2 < n_my) {
-      decode(vb + (m + 2) * nb, n2b, n2o);
+      advance(n2b, n2o);
       if (pre && !(A.dbg & 64)) issue_item(n2b, n2o);
     }
     lds_barrier();                              // B1
@@ -423,6 +443,26 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
     }
   };
 
+  // the block's items are nb apart: (sample, box coordinates) advance by mixed-radix counters, no divisions
+  int sb_, sc_[4];
+  {
+    int so_[4];
+    decode(nb, sb_, so_);
+#pragma unroll
+    for (int mu = 0; mu < 4; ++mu) sc_[mu] = so_[mu];
+  }
+  auto advance = [&](int &b, int (&o)[4]) {
+    int carry = 0;
+#pragma unroll
+    for (int mu = 3; mu >= 0; --mu) {
+      o[mu] += sc_[mu] + carry * A.box[mu];
+      const int lim = A.nbox[mu] * A.box[mu];
+      carry = o[mu] >= lim ? 1 : 0;
+      o[mu] -= carry ? lim : 0;
+    }
+    b += sb_ + carry;
+  };
+
   // ---- weights: all 27 slices, hi and lo
   const f16x8 *__restrict__ wsp = static_cast<const f16x8 *>(A.wfrag) + lane;
   f16x8 bh[27], bl[27];
@@ -454,9 +494,12 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
   f16x8 qh[8], ql[8];
   auto issue_item = [&](int b, const int (&o)[4]) {
     const unsigned char *__restrict__ src = static_cast<const unsigned char *>(A.in) + (int64_t(b) * A.V + xs) * 32;
+    const int myoff = row_offset(o, 16 * wave + (lane & 15));     // lane l: this wave's l-th halo row (one evaluation per item)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const unsigned char *q = src + int64_t(row_offset(o, 16 * wave + 2 * i + rs)) * 32;
+      const int oa = __builtin_amdgcn_readlane(myoff, 2 * i);
+      const int ob = __builtin_amdgcn_readlane(myoff, 2 * i + 1);
+      const unsigned char *q = src + int64_t(rs ? ob : oa) * 32;
       qh[i] = *reinterpret_cast<const f16x8 *>(q);
       ql[i] = *reinterpret_cast<const f16x8 *>(q + 16);
     }
@@ -484,7 +527,7 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
 #pragma unroll
   for (int mu = 0; mu < 4; ++mu) n1o[mu] = co4[mu];
   if (n_my > 1) {
-    decode(vb + nb, n1b, n1o);
+    advance(n1b, n1o);
     issue_item(n1b, n1o);
   }
   lds_barrier();
@@ -510,6 +553,7 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt][1], bh[r], acc[mt], 0, 0, 0);
     };
+    if (!(A.dbg & 1)) {
     fetch(aA, 0);
     fetch(aB, 1);
 #pragma unroll
@@ -527,25 +571,35 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
       mult(aC, r + 2);
       __builtin_amdgcn_sched_barrier(0);
     }
+    }
     // bias + activation -> ot[co][box row][x3]: rows of D = pairs 4g + r of the tile
+    if (A.act == kActTanh) {          // one straight-line copy for the common activation (code size: see conv_c1_kernel)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int zr = 2 * wave + mt;
+      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = acc[mt][r] * kInvWScale + bv;
-        ot[co * GS_CS + zr * 32 + 2 * ((g << 2) + r) + shift] = A.act == kActTanh ? fast_tanh(v) : activate(v, A.act);
-      }
+        for (int r = 0; r < 4; ++r) acc[mt][r] = fast_tanh(acc[mt][r] * kInvWScale + bv);
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mt][r] = activate(acc[mt][r] * kInvWScale + bv, kActSigmoid);
+    }
+    {
+      float *o0 = ot + co * GS_CS + (2 * wave) * 32 + 8 * g + shift;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o0[mt * 32 + 2 * r] = acc[mt][r];
     }
     // the next item's image (loads issued one iteration ago), then the loads of the one after
-    if (m + 1 < n_my) commit_item(smem_g + ((m + 1) & 1) * 2 * IMG);
+    if (m + 1 < n_my && !(A.dbg & 2)) commit_item(smem_g + ((m + 1) & 1) * 2 * IMG);
     int n2b = n1b, n2o[4] = {n1o[0], n1o[1], n1o[2], n1o[3]};
     if (m + 2 < n_my) {
-      decode(vb + (m + 2) * nb, n2b, n2o);
-      issue_item(n2b, n2o);
+      advance(n2b, n2o);
+      if (!(A.dbg & 2)) issue_item(n2b, n2o);
     }
     lds_barrier();                  // B1: ot complete, next image complete, this image consumed
-    {
+    if (!(A.dbg & 4)) {
       // one site per thread: 8 channels -> fp16 (hi, lo) -> 32 bytes
       const int t = threadIdx.x;
       const int zr = t >> 5, x3 = t & 31;
@@ -609,6 +663,10 @@ extern "C" int nf_conv_fwd_split16(const void *in16, const void *wsplit, const v
     nboxes *= A.nbox[mu];
   }
   A.cin = 8; A.cout = 8; A.act = act;
+  {
+    static const int dbg = getenv("NF_CONVG_DBG") ? atoi(getenv("NF_CONVG_DBG")) : 0;     // timing ablations: 1 no MFMA loop, 2 no staging, 4 no output
+    A.dbg = dbg;
+  }
   A.nitems = B * nboxes;
   A.nboxes = int(nboxes);
   NF_REQUIRE(A.nitems < (int64_t(1) << 31) - 4096, "nf_conv_fwd_split16: batch x boxes >= 2^31 work items, split the batch");
