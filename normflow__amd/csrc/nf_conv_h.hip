@@ -33,13 +33,15 @@ namespace h {
 constexpr int H0 = 4, H1 = 4, H2 = 4, H3 = 34;            // halo box of a 2x2x2x32 box under a 3^4 kernel
 constexpr int NSITE = H0 * H1 * H2 * H3;                  // 2176
 constexpr int NROW = H0 * H1 * H2;                        // 64 halo rows: one per lane of the loader wave
-constexpr int IMG = NSITE * 16;                           // bytes of one fp16 image (8 channels = 16 bytes per site)
+constexpr int IMG = NSITE * 16 + 256;                     // bytes of one fp16 image (8 channels = 16 bytes per site) + bank skew
 // An image is two sub-images [parity pi of the halo index z3][row][17 entries of 16 bytes]: the 16 lanes of a k-group of
 // an A fragment (v_mfma_f32_16x16x32_f16: k-group g = the 8 channels of ONE tap) read sites of one parity -- active
 // sites sit at stride 2 -- i.e. 16 consecutive entries = 256 contiguous bytes, no bank conflict.  (In plain site order
 // the same read strides 32 bytes: a 4-way conflict, measured 35 instead of ~18 cycles per MFMA.)
 constexpr int ROWB = 17 * 16;                             // bytes of a row in a sub-image
-constexpr int SUB = NROW * ROWB;                          // 17408 bytes
+constexpr int SUB = NROW * ROWB + 128;                    // 17408 bytes + half a bank period: the mover's 16-byte stores alternate
+                                                          // between the two parities lane by lane; without the skew both streams
+                                                          // land on the same banks (commit 5.7k -> cycles per item, measured)
 __host__ __device__ constexpr int rowidx(int r) { return ((r / 9) * H1 + (r / 3) % 3) * H2 + r % 3; }   // kernel row -> halo row step
 // K slices of 32 = (4 kernel rows) x (8 channels) at ONE tap j3 of the fastest axis: slice sl = 7*j3 + i holds kernel
 // rows 4i .. 4i+3 (row 27 is padding: zero weights).  Same j3 for the four k-groups => same parity sub-image.
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     if (m > 0 && !(A.dbg & 128)) epilogue(pb, po, int64_t(vb) + int64_t(m - 1) * nb);     // dbg 128: timing ablation
     prefetch_x(cb, co4);                        // for the epilogue of item m, one iteration from now
     if (m + 1 < n_my && !(A.dbg & 64)) {        // dbg 64: timing ablation
-      if (pre) commit_item(smem_h + ((m + 1) & 1) * 2 * IMG);
+      if (pre) { if (!(A.dbg & 512)) commit_item(smem_h + ((m + 1) & 1) * 2 * IMG); }     // dbg 512: timing ablation, loads only
       else stage(n1b, n1o, smem_h + ((m + 1) & 1) * 2 * IMG);
     }
     int n2b = n1b, n2o[4] = {n1o[0], n1o[1], n1o[2], n1o[3]};
