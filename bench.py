@@ -270,11 +270,20 @@ def main():
                 # (fp32-equivalent) rate; the peak that bounds it is the fp16 matrix peak / 3.  Executed fp16 flops per
                 # algorithmic flop: 3 products x 84/81 (K slices padded to 4 kernel rows) x 48/46 (columns padded to 3 tiles).
                 peak = MFMA_F16_PEAK_TFLOPS / 3.0
+                h_traffic, h_traffic_src = None, None
+                try:
+                    prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv.json")))["split16_kernels"]
+                    if lattice == (32, 32, 32, 32) and a.knots == 16:
+                        h_traffic = (prof["kernels"]["void nf::conv_h_kernel<1>(nf::ConvArgs)"]["traffic_bytes_per_launch"]
+                                     * ft["slab"] / prof["slab_batch"])
+                        h_traffic_src = "profiles/r01_pmc_conv.json (split16_kernels)"
+                except (OSError, KeyError, ValueError):
+                    pass
                 executed = ft["tflops"] * 3.0 * (84.0 / 81.0) * (48.0 / 46.0)
                 roof = {"kernel": "nf::conv_h_kernel<fwd> (last conv layer 8->46 at the active sites + RQ-spline coupling epilogue, "
                                   "fp32 products as 3 x v_mfma_f32_16x16x32_f16; dominant kernel of the timed region)",
                         "bound": "mfma", "achieved": ft["tflops"], "peak": peak, "unit": "TFLOP/s",
-                        "frac": ft["tflops"] / peak, "traffic": None, "traffic_source": None,
+                        "frac": ft["tflops"] / peak, "traffic": h_traffic, "traffic_source": h_traffic_src,
                         "launch_ms": 1e3 * ft["seconds"], "slab_batch": ft["slab"],
                         "algorithmic_flops_per_launch": ft["flops"],
                         "peak_note": "dense fp16 MFMA peak 2500 TFLOP/s / 3 fp16 products per fp32 product",
