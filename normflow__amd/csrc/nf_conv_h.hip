@@ -594,11 +594,12 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
         for (int r = 0; r < 4; ++r) o0[mt * 32 + 2 * r] = acc[mt][r];
     }
     // the next item's image (loads issued one iteration ago), then the loads of the one after
-    if (m + 1 < n_my && !(A.dbg & 2)) commit_item(smem_g + ((m + 1) & 1) * 2 * IMG);
+    if (m + 1 < n_my && !(A.dbg & 2) && !(A.dbg & 8)) commit_item(smem_g + ((m + 1) & 1) * 2 * IMG);     // dbg 8: loads without the LDS writes
     int n2b = n1b, n2o[4] = {n1o[0], n1o[1], n1o[2], n1o[3]};
     if (m + 2 < n_my) {
       advance(n2b, n2o);
       if (!(A.dbg & 2)) issue_item(n2b, n2o);
+      if (A.dbg & 8) { asm volatile("" :: "v"(qh[0][0]), "v"(ql[7][0])); }        // keep the loads alive
     }
     lds_barrier();                  // B1: ot complete, next image complete, this image consumed
     if (!(A.dbg & 4)) {

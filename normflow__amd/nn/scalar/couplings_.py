@@ -9,6 +9,8 @@ ONE fused kernel launch (+ a tiny reduction epilogue) through `normflow__amd._hi
 """
 from abc import ABC, abstractmethod
 
+import os
+
 import torch
 
 from .._core import Module_
@@ -209,7 +211,7 @@ class RQSplineCoupling_(Coupling_):
         return _hip.make_rqs_opts(m, self.xlim, self.ylim, self.extrap, layout, kx, ky)
 
     # Largest hidden-activation tensor (bytes) the fused path materialises at once.
-    HIDDEN_SLAB_BYTES = 8 << 30
+    HIDDEN_SLAB_BYTES = int(float(os.environ.get("NF_HIDDEN_SLAB_GIB", "8")) * (1 << 30))     # fp32-equivalent bytes of hidden activations per slab
 
     def _fused_atom(self, inverse, x_active, x_frozen, parity, net, log0):
         """Inference fast path: ConvAct's last layer and the spline in ONE kernel (nf_conv_rqs);
