@@ -419,15 +419,33 @@ int launch_conv_h(const ConvArgs &A0, int64_t B, int64_t nboxes, int fuse, hipSt
 // slower ones: the layer turns from MFMA-bound into data movement (32 B in, 32 B out per site), so the structure is the
 // first layer's (conv_c1_kernel): persistent workgroups, an item's input loads parked in registers for a whole
 // iteration, output through an LDS transpose.
-namespace h {
-constexpr int GS_CS = 256 + 8;                            // channel stride of the output transpose (floats)
-constexpr int G_LDS = 4 * IMG + 8 * GS_CS * 4;
-}
+// BZ2 = box extent along axis 2 (2 or 4): the 2x2x4x32 box halves the per-item overhead and cuts the halo re-reads from
+// 8.5x to 6.4x; its image does not fit LDS twice, so there is ONE image per workgroup and the item loop is
+//   compute(m) | barrier | commit image(m+1), store item m, issue loads(m+2) | barrier.
+template <int BZ2>
+struct GeoG {
+  static constexpr int H1 = 4, H2 = BZ2 + 2, H3 = 34;
+  static constexpr int NROW = 4 * H1 * H2;                  // halo rows
+  static constexpr int ROWB = 17 * 16;
+  static constexpr int SUB = NROW * ROWB + 128;             // parity sub-image (+ bank skew)
+  static constexpr int IMG = 2 * SUB;                       // one fp16 image (hi or lo)
+  static constexpr int NTILE = 4 * BZ2;                     // site tiles (= box rows of 16 pairs)
+  static constexpr int TPW = NTILE / 4;                     // tiles per wave
+  static constexpr int SITES = 32 * NTILE;
+  static constexpr int CS = SITES + 8;                      // channel stride of the output transpose (floats)
+  static constexpr int RPW = NROW / 4;                      // halo rows staged per wave
+  static constexpr int NPASS = RPW / 2;                     // two rows per pass
+  static constexpr int LDS = 2 * IMG + 8 * CS * 4;
+  static __host__ __device__ constexpr int rowidx(int r) { return ((r / 9) * H1 + (r / 3) % 3) * H2 + r % 3; }
+};
 
+template <int BZ2>
 __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
-  using namespace h;
+  typedef GeoG<BZ2> G;
+  using h::kInvWScale;
   extern __shared__ __align__(16) unsigned char smem_g[];
-  float *ot = reinterpret_cast<float *>(smem_g + 4 * IMG);
+  unsigned char *imgH = smem_g, *imgL = smem_g + G::IMG;
+  float *ot = reinterpret_cast<float *>(smem_g + 2 * G::IMG);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4;
@@ -444,9 +462,7 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
       bid /= A.nbox[mu];
     }
   };
-
-  // the block's items are nb apart: (sample, box coordinates) advance by mixed-radix counters, no divisions
-  int sb_, sc_[4];
+  int sb_, sc_[4];                  // mixed-radix digits of the item stride nb: no divisions in the loop
   {
     int so_[4];
     decode(nb, sb_, so_);
@@ -475,30 +491,30 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
   }
   const int col = lane & 15, co = col & 7, shift = col >> 3;
   const float bv = (A.bias && co < A.cout) ? static_cast<const float *>(A.bias)[co] : 0.f;
-  // ---- A reads: tile = box row zr = 2*wave + mt; lane (pair p, tap g): parity g & 1, entry p + (g >> 1)
-  int T[2];
+  // ---- A reads: tile = box row zr = TPW*wave + mt; lane (pair p, tap g): parity g & 1, entry p + (g >> 1)
+  int T[G::TPW];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int zr = 2 * wave + mt;
-    const int r0 = ((zr >> 2) * H1 + ((zr >> 1) & 1)) * H2 + (zr & 1);
-    T[mt] = (g & 1) * SUB + (r0 * 17 + (lane & 15) + (g >> 1)) * 16;
+  for (int mt = 0; mt < G::TPW; ++mt) {
+    const int zr = G::TPW * wave + mt;
+    const int r0 = ((zr / (2 * BZ2)) * G::H1 + (zr / BZ2) % 2) * G::H2 + zr % BZ2;
+    T[mt] = (g & 1) * G::SUB + (r0 * 17 + (lane & 15) + (g >> 1)) * 16;
   }
-  // ---- staging: wave w copies halo rows 16w .. 16w+15, two per pass (lanes 0-31 / 32-63), one interior site per lane
+  // ---- staging: wave w copies halo rows RPW*w .. RPW*w + RPW - 1, two per pass, one interior site per lane
   const int rs = lane >> 5, xs = lane & 31;
-  auto row_offset = [&](const int (&o)[4], int row) {       // offset (sites) of halo row `row` in the input
-    const int z0 = row / (H1 * H2), z1 = (row / H2) % H1, z2 = row % H2;
+  auto row_offset = [&](const int (&o)[4], int row) {
+    const int z0 = row / (G::H1 * G::H2), z1 = (row / G::H2) % G::H1, z2 = row % G::H2;
     int x0 = o[0] + z0 - 1, x1 = o[1] + z1 - 1, x2 = o[2] + z2 - 1;
     x0 = x0 < 0 ? x0 + A.L[0] : (x0 >= A.L[0] ? x0 - A.L[0] : x0);
     x1 = x1 < 0 ? x1 + A.L[1] : (x1 >= A.L[1] ? x1 - A.L[1] : x1);
     x2 = x2 < 0 ? x2 + A.L[2] : (x2 >= A.L[2] ? x2 - A.L[2] : x2);
     return ((x0 * A.L[1] + x1) * A.L[2] + x2) * A.L[3];
   };
-  f16x8 qh[8], ql[8];
+  f16x8 qh[G::NPASS], ql[G::NPASS];
   auto issue_item = [&](int b, const int (&o)[4]) {
     const unsigned char *__restrict__ src = static_cast<const unsigned char *>(A.in) + (int64_t(b) * A.V + xs) * 32;
-    const int myoff = row_offset(o, 16 * wave + (lane & 15));     // lane l: this wave's l-th halo row (one evaluation per item)
+    const int myoff = row_offset(o, G::RPW * wave + (lane < G::RPW ? lane : 0));     // lane l: this wave's l-th halo row
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < G::NPASS; ++i) {
       const int oa = __builtin_amdgcn_readlane(myoff, 2 * i);
       const int ob = __builtin_amdgcn_readlane(myoff, 2 * i + 1);
       const unsigned char *q = src + int64_t(rs ? ob : oa) * 32;
@@ -506,25 +522,25 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
       ql[i] = *reinterpret_cast<const f16x8 *>(q + 16);
     }
   };
-  auto put = [&](unsigned char *imgH, int row, int z3, const f16x8 &hi, const f16x8 &lo) {
-    const int d = (z3 & 1) * SUB + (row * 17 + (z3 >> 1)) * 16;
+  auto put = [&](int row, int z3, const f16x8 &hi, const f16x8 &lo) {
+    const int d = (z3 & 1) * G::SUB + (row * 17 + (z3 >> 1)) * 16;
     *reinterpret_cast<f16x8 *>(imgH + d) = hi;
-    *reinterpret_cast<f16x8 *>(imgH + IMG + d) = lo;
+    *reinterpret_cast<f16x8 *>(imgL + d) = lo;
   };
-  auto commit_item = [&](unsigned char *imgH) {
+  auto commit_item = [&]() {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = 16 * wave + 2 * i + rs;
-      put(imgH, row, xs + 1, qh[i], ql[i]);
-      if (xs == 0) put(imgH, row, H3 - 1, qh[i], ql[i]);     // periodic copies of the row's end sites
-      if (xs == 31) put(imgH, row, 0, qh[i], ql[i]);
+    for (int i = 0; i < G::NPASS; ++i) {
+      const int row = G::RPW * wave + 2 * i + rs;
+      put(row, xs + 1, qh[i], ql[i]);
+      if (xs == 0) put(row, G::H3 - 1, qh[i], ql[i]);          // periodic copies of the row's end sites
+      if (xs == 31) put(row, 0, qh[i], ql[i]);
     }
   };
 
   int cb, co4[4], n1b, n1o[4];
   decode(vb, cb, co4);
   issue_item(cb, co4);
-  commit_item(smem_g);
+  commit_item();
   n1b = cb;
 #pragma unroll
   for (int mu = 0; mu < 4; ++mu) n1o[mu] = co4[mu];
@@ -534,93 +550,95 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
   }
   lds_barrier();
   for (int m = 0; m < n_my; ++m) {
-    const unsigned char *imgH = smem_g + (m & 1) * 2 * IMG;
-    const unsigned char *imgL = imgH + IMG;
-    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    // 27 slices, A fragments read two slices ahead (three named buffers)
-    f16x8 aA[2][2], aB[2][2], aC[2][2];            // [tile][hi|lo]
-    auto fetch = [&](f16x8 (&a)[2][2], int r) {
-      const int off = rowidx(r) * ROWB;
+    f32x4 acc[G::TPW];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < G::TPW; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // 27 slices (one per kernel row), A fragments read two slices ahead (three named buffers)
+    f16x8 aA[G::TPW][2], aB[G::TPW][2], aC[G::TPW][2];            // [tile][hi|lo]
+    auto fetch = [&](f16x8 (&a)[G::TPW][2], int r) {
+      const int off = G::rowidx(r) * G::ROWB;
+#pragma unroll
+      for (int mt = 0; mt < G::TPW; ++mt) {
         a[mt][0] = *reinterpret_cast<const f16x8 *>(imgH + T[mt] + off);
         a[mt][1] = *reinterpret_cast<const f16x8 *>(imgL + T[mt] + off);
       }
     };
-    auto mult = [&](const f16x8 (&a)[2][2], int r) {
+    auto mult = [&](const f16x8 (&a)[G::TPW][2], int r) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt][0], bh[r], acc[mt], 0, 0, 0);
+      for (int mt = 0; mt < G::TPW; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt][0], bh[r], acc[mt], 0, 0, 0);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt][0], bl[r], acc[mt], 0, 0, 0);
+      for (int mt = 0; mt < G::TPW; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt][0], bl[r], acc[mt], 0, 0, 0);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt][1], bh[r], acc[mt], 0, 0, 0);
+      for (int mt = 0; mt < G::TPW; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt][1], bh[r], acc[mt], 0, 0, 0);
     };
     if (!(A.dbg & 1)) {
-    fetch(aA, 0);
-    fetch(aB, 1);
+      fetch(aA, 0);
+      fetch(aB, 1);
 #pragma unroll
-    for (int r = 0; r < 27; r += 3) {
-      fetch(aC, r + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      mult(aA, r);
-      __builtin_amdgcn_sched_barrier(0);
-      if (r + 3 < 27) fetch(aA, r + 3);
-      __builtin_amdgcn_sched_barrier(0);
-      mult(aB, r + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (r + 4 < 27) fetch(aB, r + 4);
-      __builtin_amdgcn_sched_barrier(0);
-      mult(aC, r + 2);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+      for (int r = 0; r < 27; r += 3) {
+        fetch(aC, r + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(aA, r);
+        __builtin_amdgcn_sched_barrier(0);
+        if (r + 3 < 27) fetch(aA, r + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(aB, r + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (r + 4 < 27) fetch(aB, r + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(aC, r + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     // bias + activation -> ot[co][box row][x3]: rows of D = pairs 4g + r of the tile
     if (A.act == kActTanh) {          // one straight-line copy for the common activation (code size: see conv_c1_kernel)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < G::TPW; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[mt][r] = fast_tanh(acc[mt][r] * kInvWScale + bv);
     } else {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < G::TPW; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[mt][r] = activate(acc[mt][r] * kInvWScale + bv, kActSigmoid);
     }
     {
-      float *o0 = ot + co * GS_CS + (2 * wave) * 32 + 8 * g + shift;
+      float *o0 = ot + co * G::CS + (G::TPW * wave) * 32 + 8 * g + shift;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < G::TPW; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) o0[mt * 32 + 2 * r] = acc[mt][r];
     }
-    // the next item's image (loads issued one iteration ago), then the loads of the one after
-    if (m + 1 < n_my && !(A.dbg & 2) && !(A.dbg & 8)) commit_item(smem_g + ((m + 1) & 1) * 2 * IMG);     // dbg 8: loads without the LDS writes
+    lds_barrier();                  // B0: the image is consumed, ot is complete
+    // next item's image (loads issued one iteration ago), this item's output, the loads of the item after next
+    if (m + 1 < n_my && !(A.dbg & 2)) commit_item();
+    if (!(A.dbg & 4)) {
+      // SITES/256 sites per thread: 8 channels -> fp16 (hi, lo) -> 32 bytes
+#pragma unroll
+      for (int k = 0; k < G::SITES / 256; ++k) {
+        const int t = threadIdx.x + 256 * k;
+        const int zr = t >> 5, x3 = t & 31;
+        f16x8 hi, lo;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float v = ot[c * G::CS + t];
+          const _Float16 hh = static_cast<_Float16>(v);
+          hi[c] = hh;
+          lo[c] = static_cast<_Float16>(v - static_cast<float>(hh));
+        }
+        const int x0 = co4[0] + zr / (2 * BZ2), x1 = co4[1] + (zr / BZ2) % 2, x2 = co4[2] + zr % BZ2;
+        unsigned char *d = static_cast<unsigned char *>(A.out) +
+                           (int64_t(cb) * A.V + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + x3) * 32;
+        *reinterpret_cast<f16x8 *>(d) = hi;
+        *reinterpret_cast<f16x8 *>(d + 16) = lo;
+      }
+    }
     int n2b = n1b, n2o[4] = {n1o[0], n1o[1], n1o[2], n1o[3]};
     if (m + 2 < n_my) {
       advance(n2b, n2o);
       if (!(A.dbg & 2)) issue_item(n2b, n2o);
-      if (A.dbg & 8) { asm volatile("" :: "v"(qh[0][0]), "v"(ql[7][0])); }        // keep the loads alive
     }
-    lds_barrier();                  // B1: ot complete, next image complete, this image consumed
-    if (!(A.dbg & 4)) {
-      // one site per thread: 8 channels -> fp16 (hi, lo) -> 32 bytes
-      const int t = threadIdx.x;
-      const int zr = t >> 5, x3 = t & 31;
-      f16x8 hi, lo;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const float v = ot[c * GS_CS + t];
-        const _Float16 hh = static_cast<_Float16>(v);
-        hi[c] = hh;
-        lo[c] = static_cast<_Float16>(v - static_cast<float>(hh));
-      }
-      const int x0 = co4[0] + (zr >> 2), x1 = co4[1] + ((zr >> 1) & 1), x2 = co4[2] + (zr & 1);
-      unsigned char *d = static_cast<unsigned char *>(A.out) +
-                         (int64_t(cb) * A.V + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + x3) * 32;
-      *reinterpret_cast<f16x8 *>(d) = hi;
-      *reinterpret_cast<f16x8 *>(d + 16) = lo;
-    }
-    lds_barrier();                  // B2: ot free
+    lds_barrier();                  // B1: the next image is complete, ot is free
     cb = n1b;
     n1b = n2b;
 #pragma unroll
@@ -657,7 +675,9 @@ extern "C" int nf_conv_fwd_split16(const void *in16, const void *wsplit, const v
   ConvArgs A{};
   A.in = in16; A.wfrag = wsplit; A.bias = bias; A.out = out16;
   A.V = 1;
-  const int box[4] = {2, 2, 2, 32};
+  static const int bz2_env = getenv("NF_CONVG_BZ2") ? atoi(getenv("NF_CONVG_BZ2")) : 0;        // A/B knob
+  const int bz2 = bz2_env == 2 ? 2 : ((lattice[2] % 4 == 0) ? 4 : 2);
+  const int box[4] = {2, 2, bz2, 32};
   int64_t nboxes = 1;
   for (int mu = 0; mu < 4; ++mu) {
     A.L[mu] = lattice[mu]; A.k[mu] = 3; A.box[mu] = box[mu];
@@ -684,8 +704,14 @@ extern "C" int nf_conv_fwd_split16(const void *in16, const void *wsplit, const v
   int64_t grid = ncu;
   if (grid > A.nitems) grid = A.nitems;
   grid = (grid + 7) & ~int64_t(7);
-  NF_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_g_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS) == hipSuccess,
-             "nf_conv_fwd_split16: cannot reserve %d B of LDS", G_LDS);
-  hipLaunchKernelGGL(conv_g_kernel, dim3(unsigned(grid)), dim3(256), G_LDS, stream, A);
+  if (bz2 == 4) {
+    NF_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_g_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, GeoG<4>::LDS) == hipSuccess,
+               "nf_conv_fwd_split16: cannot reserve %d B of LDS", GeoG<4>::LDS);
+    hipLaunchKernelGGL(conv_g_kernel<4>, dim3(unsigned(grid)), dim3(256), GeoG<4>::LDS, stream, A);
+  } else {
+    NF_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_g_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, GeoG<2>::LDS) == hipSuccess,
+               "nf_conv_fwd_split16: cannot reserve %d B of LDS", GeoG<2>::LDS);
+    hipLaunchKernelGGL(conv_g_kernel<2>, dim3(unsigned(grid)), dim3(256), GeoG<2>::LDS, stream, A);
+  }
   return check_launch("conv split-fp16 two-site kernel");
 }

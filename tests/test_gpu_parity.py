@@ -994,12 +994,12 @@ def test_split_fp16_fused_last_layer(shape, B):
         assert rel(yf[:nb], yo) <= 1e-5 and rel(lf[:nb], lo) <= 1e-5
 
 
-def test_split_fp16_hidden_layer_and_chain():
+@pytest.mark.parametrize("shape,B", [((4, 2, 6, 32), 40), ((2, 4, 8, 32), 45), ((2, 2, 4, 32), 300)])
+def test_split_fp16_hidden_layer_and_chain(shape, B):
     """conv_g_kernel (8 -> 8 hidden layer on fp16 (hi, lo) pairs in and out) against the fp64 definition, and the whole
     split chain of a ConvAct stack (first layer writes the pairs, hidden layer, fused last layer) against the fp32
     kernels and the oracle."""
     torch.manual_seed(23)
-    shape, B = (4, 2, 6, 32), 40
     V = int(np.prod(shape))
     g = torch.Generator(device='cpu').manual_seed(5)
     h = torch.tanh(torch.randn((B, 8) + shape, generator=g, dtype=torch.float64, device='cpu'))
