@@ -1031,3 +1031,40 @@ def test_split_fp16_hidden_layer_and_chain(shape, B):
     y2, lj2 = cpl(x[:3].clone().requires_grad_(True))          # fp32 kernels, logits materialised
     assert rel(y2, y[:3]) <= 5e-6 and rel(lj2, lj[:3]) <= 5e-6
     assert rel(xb, x) <= 5e-4 and float(lb.abs().max()) <= 5e-4 * max(1.0, float(lj.abs().max()))
+
+
+def test_split_fp16_guards_and_graph_replay():
+    """(a) weights outside the split kernel's range (|w| * 2^10 >= 3e4) fall back to the fp32 kernels, same results
+    within tolerance; (b) the split chain is capturable: GraphedFlow replays it bitwise."""
+    from normflow__amd import GraphedFlow
+    torch.manual_seed(31)
+    shape, B = (2, 2, 4, 32), 5
+    net = ConvAct(1, 46, 3, conv_dim=4, hidden_sizes=[8, 8], acts=['tanh', 'tanh', None]).to(DEV, torch.float32)
+    with torch.no_grad():
+        for p_ in list(net.parameters())[-2:]:
+            p_.mul_(0.3)
+    mask = EvenOddMask(shape=shape)
+    lim = dict(xlim=(-5.0, 5.0), ylim=(-5.0, 5.0), extrap={'left': 'linear', 'right': 'linear'})
+    cpl = RQSplineCoupling_([net, net], mask=mask, **lim).to(DEV)
+    x = torch.randn((B,) + shape, device=DEV, dtype=torch.float32)
+    with torch.no_grad():
+        y, lj = cpl(x)
+    assert _hip.load().nf_conv_last_path() == 3
+    g = GraphedFlow(cpl, x)
+    xn = torch.randn_like(x)
+    with torch.no_grad():
+        y1, l1 = cpl(xn)
+    y2, l2 = g(xn)
+    assert torch.equal(y1, y2) and torch.equal(l1, l2)
+    # one huge (but harmless: multiplied by a zero input channel weight elsewhere) weight switches the split path off
+    last = [mod for mod in net if hasattr(mod, 'weight')][-1]
+    with torch.no_grad():
+        w_old = last.weight[0, 0, 0, 0, 0, 0].item()
+        last.weight[0, 0, 0, 0, 0, 0] = 40.0
+        y3, l3 = cpl(x)
+        assert _hip.load().nf_conv_last_path() != 3
+        y4, l4 = cpl(x[:2].clone().requires_grad_(True))
+        assert rel(y4, y3[:2]) <= 5e-6 and rel(l4, l3[:2]) <= 5e-6
+        last.weight[0, 0, 0, 0, 0, 0] = w_old
+        y5, l5 = cpl(x)
+    assert _hip.load().nf_conv_last_path() == 3 and torch.equal(y5, y) and torch.equal(l5, lj)
