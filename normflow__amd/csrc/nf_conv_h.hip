@@ -33,15 +33,13 @@ namespace h {
 constexpr int H0 = 4, H1 = 4, H2 = 4, H3 = 34;            // halo box of a 2x2x2x32 box under a 3^4 kernel
 constexpr int NSITE = H0 * H1 * H2 * H3;                  // 2176
 constexpr int NROW = H0 * H1 * H2;                        // 64 halo rows: one per lane of the loader wave
-constexpr int IMG = NSITE * 16 + 256;                     // bytes of one fp16 image (8 channels = 16 bytes per site) + bank skew
+constexpr int IMG = NSITE * 16;                           // bytes of one fp16 image (8 channels = 16 bytes per site)
 // An image is two sub-images [parity pi of the halo index z3][row][17 entries of 16 bytes]: the 16 lanes of a k-group of
 // an A fragment (v_mfma_f32_16x16x32_f16: k-group g = the 8 channels of ONE tap) read sites of one parity -- active
 // sites sit at stride 2 -- i.e. 16 consecutive entries = 256 contiguous bytes, no bank conflict.  (In plain site order
 // the same read strides 32 bytes: a 4-way conflict, measured 35 instead of ~18 cycles per MFMA.)
 constexpr int ROWB = 17 * 16;                             // bytes of a row in a sub-image
-constexpr int SUB = NROW * ROWB + 128;                    // 17408 bytes + half a bank period: the mover's 16-byte stores alternate
-                                                          // between the two parities lane by lane; without the skew both streams
-                                                          // land on the same banks (commit 5.7k -> cycles per item, measured)
+constexpr int SUB = NROW * ROWB;                          // 17408 bytes (a half-bank-period skew between the two parities: no effect)
 __host__ __device__ constexpr int rowidx(int r) { return ((r / 9) * H1 + (r / 3) % 3) * H2 + r % 3; }   // kernel row -> halo row step
 // K slices of 32 = (4 kernel rows) x (8 channels) at ONE tap j3 of the fastest axis: slice sl = 7*j3 + i holds kernel
 // rows 4i .. 4i+3 (row 27 is padding: zero weights).  Same j3 for the four k-groups => same parity sub-image.
