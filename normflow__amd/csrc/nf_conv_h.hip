@@ -142,38 +142,40 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       for (int mt = 0; mt < 8; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
       // 21 slices of 8 site tiles; A fragments (hi, lo: 16 + 16 bytes per lane and tile) are read one slice ahead; the 24
       // MFMAs of a slice run hi*hi over the 8 tiles, then hi*lo, then lo*hi: an accumulator is touched every 8th MFMA.
-      f16x8 ahA[8], alA[8], ahB[8], alB[8];
-      auto fetch = [&](f16x8 (&ah)[8], f16x8 (&al)[8], int sl) {
+      // 42 half-slices (4 site tiles each): finer interleaving of the fragment reads with the MFMAs keeps the three waves'
+      // LDS requests from arriving in 16 KB bursts
+      f16x8 ahA[4], alA[4], ahB[4], alB[4];
+      auto fetch = [&](f16x8 (&ah)[4], f16x8 (&al)[4], int hs) {
+        const int sl = hs >> 1, t0 = (hs & 1) * 4;
         const int j3 = sl / 7, i = sl % 7;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const int a = T[t][j3] + RG[i];
+        for (int t = 0; t < 4; ++t) {
+          const int a = T[t0 + t][j3] + RG[i];
           ah[t] = *reinterpret_cast<const f16x8 *>(imgH + a);
           al[t] = *reinterpret_cast<const f16x8 *>(imgL + a);
         }
       };
-      auto mult = [&](const f16x8 (&ah)[8], const f16x8 (&al)[8], int sl) {
+      auto mult = [&](const f16x8 (&ah)[4], const f16x8 (&al)[4], int hs) {
+        const int sl = hs >> 1, t0 = (hs & 1) * 4;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[sl], acc[t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) acc[t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[sl], acc[t0 + t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[sl], acc[t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) acc[t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[sl], acc[t0 + t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[sl], acc[t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) acc[t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[sl], acc[t0 + t], 0, 0, 0);
       };
       if (!(A.dbg & 256)) {     // dbg 256: timing ablation, no MFMA loop
         fetch(ahA, alA, 0);
 #pragma unroll
-        for (int sl = 0; sl < NS; sl += 2) {
-          if (sl + 1 < NS) fetch(ahB, alB, sl + 1);
+        for (int hs = 0; hs < 2 * NS; hs += 2) {
+          fetch(ahB, alB, hs + 1);
           __builtin_amdgcn_sched_barrier(0);
-          mult(ahA, alA, sl);
+          mult(ahA, alA, hs);
           __builtin_amdgcn_sched_barrier(0);
-          if (sl + 1 < NS) {
-            if (sl + 2 < NS) fetch(ahA, alA, sl + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            mult(ahB, alB, sl + 1);
-            __builtin_amdgcn_sched_barrier(0);
-          }
+          if (hs + 2 < 2 * NS) fetch(ahA, alA, hs + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          mult(ahB, alB, hs + 1);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       lds_barrier();            // B1: this image is consumed; the mover is done with the previous logits and the next image
@@ -336,9 +338,26 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       ql[i] = *reinterpret_cast<const f16x8 *>(q + 16);
     }
   };
+  // lane-constant parts of the LDS addresses (row = 2i + rs): the main store of the lane's site and, on the two edge
+  // lanes of a row, the periodic copy; per pass only an immediate row offset is added and ONE branch guards the copies
+  const int d_main = ((xs + 1) & 1) * SUB + (rs * 17 + ((xs + 1) >> 1)) * 16;
+  const bool edge = xs == 0 || xs == 31;
+  const int d_edge = xs == 0 ? SUB + (rs * 17 + 16) * 16 : (rs * 17) * 16;      // site 0 -> halo index 33 (odd, entry 16); site 31 -> index 0
   auto commit_item = [&](unsigned char *imgH) {
 #pragma unroll
-    for (int i = 0; i < NROW / 2; ++i) put3(imgH, 2 * i + rs, qh[i], ql[i]);
+    for (int i = 0; i < NROW / 2; ++i) {
+      unsigned char *p0 = imgH + d_main + i * (2 * ROWB);
+      *reinterpret_cast<f16x8 *>(p0) = qh[i];
+      *reinterpret_cast<f16x8 *>(p0 + IMG) = ql[i];
+    }
+    if (edge) {
+#pragma unroll
+      for (int i = 0; i < NROW / 2; ++i) {
+        unsigned char *p1 = imgH + d_edge + i * (2 * ROWB);
+        *reinterpret_cast<f16x8 *>(p1) = qh[i];
+        *reinterpret_cast<f16x8 *>(p1 + IMG) = ql[i];
+      }
+    }
   };
   int n1b = cb, n1o[4] = {co4[0], co4[1], co4[2], co4[3]};      // item m + 1 (in registers when pre)
   if (n_my > 1) advance(n1b, n1o);
@@ -520,18 +539,26 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
       ql[i] = *reinterpret_cast<const f16x8 *>(q + 16);
     }
   };
-  auto put = [&](int row, int z3, const f16x8 &hi, const f16x8 &lo) {
-    const int d = (z3 & 1) * G::SUB + (row * 17 + (z3 >> 1)) * 16;
-    *reinterpret_cast<f16x8 *>(imgH + d) = hi;
-    *reinterpret_cast<f16x8 *>(imgL + d) = lo;
-  };
+  // lane-constant parts of the LDS addresses (row = RPW*wave + 2i + rs): main store and, on the two edge lanes of a row,
+  // the periodic copy; per pass an immediate row offset is added and one branch guards all the copies
+  const int rbase = G::RPW * wave + rs;
+  const int d_main = ((xs + 1) & 1) * G::SUB + (rbase * 17 + ((xs + 1) >> 1)) * 16;
+  const bool edge = xs == 0 || xs == 31;
+  const int d_edge = xs == 0 ? G::SUB + (rbase * 17 + 16) * 16 : (rbase * 17) * 16;
   auto commit_item = [&]() {
 #pragma unroll
     for (int i = 0; i < G::NPASS; ++i) {
-      const int row = G::RPW * wave + 2 * i + rs;
-      put(row, xs + 1, qh[i], ql[i]);
-      if (xs == 0) put(row, G::H3 - 1, qh[i], ql[i]);          // periodic copies of the row's end sites
-      if (xs == 31) put(row, 0, qh[i], ql[i]);
+      unsigned char *p0 = imgH + d_main + i * (2 * G::ROWB);
+      *reinterpret_cast<f16x8 *>(p0) = qh[i];
+      *reinterpret_cast<f16x8 *>(p0 + G::IMG) = ql[i];
+    }
+    if (edge) {
+#pragma unroll
+      for (int i = 0; i < G::NPASS; ++i) {
+        unsigned char *p1 = imgH + d_edge + i * (2 * G::ROWB);
+        *reinterpret_cast<f16x8 *>(p1) = qh[i];
+        *reinterpret_cast<f16x8 *>(p1 + G::IMG) = ql[i];
+      }
     }
   };
 
