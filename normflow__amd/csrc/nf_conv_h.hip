@@ -328,14 +328,15 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   f16x8 qh[NROW / 2], ql[NROW / 2];
   auto issue_item = [&](int b, const int (&o)[4]) {
     const int myoff = row_offsets(o);
-    const unsigned char *__restrict__ src = static_cast<const unsigned char *>(A.in) + (int64_t(b) * A.V + xs) * 32;
+    // uniform 64-bit base + 32-bit per-lane byte offset (a sample is V*32 < 2^32 bytes): scalar-base addressing
+    const unsigned char *__restrict__ src = static_cast<const unsigned char *>(A.in) + int64_t(b) * A.V * 32;
 #pragma unroll
     for (int i = 0; i < NROW / 2; ++i) {
-      const int oa = __builtin_amdgcn_readlane(myoff, 2 * i);
-      const int ob = __builtin_amdgcn_readlane(myoff, 2 * i + 1);
-      const unsigned char *q = src + int64_t(rs ? ob : oa) * 32;
-      qh[i] = *reinterpret_cast<const f16x8 *>(q);
-      ql[i] = *reinterpret_cast<const f16x8 *>(q + 16);
+      const unsigned oa = unsigned(__builtin_amdgcn_readlane(myoff, 2 * i));
+      const unsigned ob = unsigned(__builtin_amdgcn_readlane(myoff, 2 * i + 1));
+      const unsigned voff = ((rs ? ob : oa) + unsigned(xs)) * 32u;
+      qh[i] = *reinterpret_cast<const f16x8 *>(src + voff);
+      ql[i] = *reinterpret_cast<const f16x8 *>(src + voff + 16u);
     }
   };
   // lane-constant parts of the LDS addresses (row = 2i + rs): the main store of the lane's site and, on the two edge
@@ -528,15 +529,15 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
   };
   f16x8 qh[G::NPASS], ql[G::NPASS];
   auto issue_item = [&](int b, const int (&o)[4]) {
-    const unsigned char *__restrict__ src = static_cast<const unsigned char *>(A.in) + (int64_t(b) * A.V + xs) * 32;
+    const unsigned char *__restrict__ src = static_cast<const unsigned char *>(A.in) + int64_t(b) * A.V * 32;
     const int myoff = row_offset(o, G::RPW * wave + (lane < G::RPW ? lane : 0));     // lane l: this wave's l-th halo row
 #pragma unroll
     for (int i = 0; i < G::NPASS; ++i) {
-      const int oa = __builtin_amdgcn_readlane(myoff, 2 * i);
-      const int ob = __builtin_amdgcn_readlane(myoff, 2 * i + 1);
-      const unsigned char *q = src + int64_t(rs ? ob : oa) * 32;
-      qh[i] = *reinterpret_cast<const f16x8 *>(q);
-      ql[i] = *reinterpret_cast<const f16x8 *>(q + 16);
+      const unsigned oa = unsigned(__builtin_amdgcn_readlane(myoff, 2 * i));
+      const unsigned ob = unsigned(__builtin_amdgcn_readlane(myoff, 2 * i + 1));
+      const unsigned voff = ((rs ? ob : oa) + unsigned(xs)) * 32u;       // uniform base + 32-bit lane offset (V*32 < 2^32)
+      qh[i] = *reinterpret_cast<const f16x8 *>(src + voff);
+      ql[i] = *reinterpret_cast<const f16x8 *>(src + voff + 16u);
     }
   };
   // lane-constant parts of the LDS addresses (row = RPW*wave + 2i + rs): main store and, on the two edge lanes of a row,
