@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+#include <type_traits>
 #include "nf_conv_core.h"
 
 namespace nf {
@@ -47,8 +48,11 @@ constexpr int NS = 21;
 constexpr int UNITS = 128;                                // active sites per box
 constexpr float kInvWScale = 1.0f / 1024.0f;              // normflow__amd/_hip.py: SPLIT16_WEIGHT_SCALE
 constexpr int C = 46, M = 16;
-constexpr int PT = C * UNITS * 4;                         // bytes of the logit scratch
+constexpr int PTS = UNITS + 4;                            // row stride of the logit scratch in floats: +4 spreads the 16 channels a
+                                                          // wave writes at once over the banks (stride 128 put them all on one)
+constexpr int PT = C * PTS * 4;                           // bytes of the logit scratch
 constexpr int LDS_BYTES = 4 * IMG + PT;
+static_assert(LDS_BYTES <= 160 * 1024, "two image pairs and the logit scratch must fit the CU's LDS");
 
 __host__ __device__ constexpr int rowoff(int r) {         // halo-site offset of kernel row r = (j0, j1, j2)
   return (((r / 9) * H1 + (r / 3) % 3) * H2 + r % 3) * H3;
@@ -99,96 +103,138 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   };
 
   if (wave < 3) {
-    // ============================================================ compute waves: column tile `wave`
-    const f16x8 *__restrict__ wsp = static_cast<const f16x8 *>(A.wfrag) + (wave * NS * 2) * 64 + lane;
-    f16x8 bh[NS], bl[NS];
+    // ============================================================ compute waves: K third `wave` = fastest-axis tap j3
+    // Wave w multiplies the 7 slices of tap j3 = w (kernel rows 4i..4i+3, i = 0..6) into ALL three column tiles of all 8
+    // site tiles: 36 MFMAs per 8 fragment reads and no fragment read by two waves (with one column tile per wave the
+    // three waves read the same 1 MB per item and the LDS pipe, not the matrix pipe, set the pace).  The three partial
+    // sums meet in the logit scratch in three rounds, every wave working on a different column tile in each round:
+    // round 0 writes, rounds 1 and 2 add (fixed order per column tile: deterministic).
+    auto body = [&](auto WC) {
+      constexpr int W = decltype(WC)::value;                  // = j3
+      f16x8 bh[7][3], bl[7][3];
+      {
+        const f16x8 *__restrict__ wsp = static_cast<const f16x8 *>(A.wfrag) + lane;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      bh[s] = wsp[(2 * s) * 64];
-      bl[s] = wsp[(2 * s + 1) * 64];
-    }
-    const int co = (wave << 4) + (lane & 15);
-    const float bv = (A.bias && co < A.cout) ? static_cast<const float *>(A.bias)[co] : 0.f;
-    // byte offset of this lane's A read = T[site tile][j3] + RG[i]: T places the lane's site (box row mt: z0 = mt>>2,
-    // z1 = (mt>>1)&1, z2 = mt&1; halo index 2p + parity + j3) in its parity sub-image, RG adds the halo rows of kernel row
-    // 4i + g.  Box extents are even, so the parity of a box row does not depend on the box.
-    int T[8][3], RG[7];
-    {
-      const int p = lane & 15;
+        for (int i = 0; i < 7; ++i)
 #pragma unroll
-      for (int mt = 0; mt < 8; ++mt) {
-        const int z0 = mt >> 2, z1 = (mt >> 1) & 1, z2 = mt & 1;
-        const int par = (A.parity + z0 + z1 + z2) & 1;
-        const int r0 = (z0 * H1 + z1) * H2 + z2;
+          for (int t = 0; t < 3; ++t) {
+            bh[i][t] = wsp[((t * NS + 7 * W + i) * 2) * 64];
+            bl[i][t] = wsp[((t * NS + 7 * W + i) * 2 + 1) * 64];
+          }
+      }
+      // byte offset of this lane's A read = T[site tile] + RG[i]: T places the lane's site (box row mt: z0 = mt>>2,
+      // z1 = (mt>>1)&1, z2 = mt&1; halo index 2p + parity + j3) in its parity sub-image, RG adds the halo rows of kernel
+      // row 4i + g.  Box extents are even, so the parity of a box row does not depend on the box.
+      int T[8], RG[7];
+      {
+        const int p = lane & 15;
 #pragma unroll
-        for (int j3 = 0; j3 < 3; ++j3) {
-          const int z3 = 2 * p + par + j3;
-          T[mt][j3] = (z3 & 1) * SUB + (r0 * 17 + (z3 >> 1)) * 16;
+        for (int mt = 0; mt < 8; ++mt) {
+          const int z0 = mt >> 2, z1 = (mt >> 1) & 1, z2 = mt & 1;
+          const int par = (A.parity + z0 + z1 + z2) & 1;
+          const int r0 = (z0 * H1 + z1) * H2 + z2;
+          const int z3 = 2 * p + par + W;
+          T[mt] = (z3 & 1) * SUB + (r0 * 17 + (z3 >> 1)) * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          const int r = 4 * i + g;
+          const int rr = r < 27 ? r : 26;
+          RG[i] = (((rr / 9) * H1 + (rr / 3) % 3) * H2 + rr % 3) * ROWB;
         }
       }
+      // columns this wave handles in the three reduction rounds
+      constexpr int N0 = W, N1 = (W + 1) % 3, N2 = (W + 2) % 3;
+      const int co2 = (N2 << 4) + (lane & 15);
+      const float bv2 = (A.bias && co2 < A.cout) ? static_cast<const float *>(A.bias)[co2] : 0.f;
+      lds_barrier();            // P: the mover has staged the first image
+      for (int m = 0; m < n_my; ++m) {
+        const unsigned char *imgH = smem_h + (m & 1) * 2 * IMG;
+        const unsigned char *imgL = imgH + IMG;
+        f32x4 acc[8][3];
 #pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        const int r = 4 * i + g;
-        const int rr = r < 27 ? r : 26;
-        RG[i] = (((rr / 9) * H1 + (rr / 3) % 3) * H2 + rr % 3) * ROWB;
-      }
-    }
-    lds_barrier();            // P: the mover has staged the first image
-    for (int m = 0; m < n_my; ++m) {
-      const unsigned char *imgH = smem_h + (m & 1) * 2 * IMG;
-      const unsigned char *imgL = imgH + IMG;
-      f32x4 acc[8];
+        for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
-      for (int mt = 0; mt < 8; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // 21 slices of 8 site tiles; A fragments (hi, lo: 16 + 16 bytes per lane and tile) are read one slice ahead; the 24
-      // MFMAs of a slice run hi*hi over the 8 tiles, then hi*lo, then lo*hi: an accumulator is touched every 8th MFMA.
-      // 42 half-slices (4 site tiles each): finer interleaving of the fragment reads with the MFMAs keeps the three waves'
-      // LDS requests from arriving in 16 KB bursts
-      f16x8 ahA[4], alA[4], ahB[4], alB[4];
-      auto fetch = [&](f16x8 (&ah)[4], f16x8 (&al)[4], int hs) {
-        const int sl = hs >> 1, t0 = (hs & 1) * 4;
-        const int j3 = sl / 7, i = sl % 7;
+          for (int t = 0; t < 3; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // 14 half-slices (4 site tiles each), fragments read one half-slice ahead
+        f16x8 ahA[4], alA[4], ahB[4], alB[4];
+        auto fetch = [&](f16x8 (&ah)[4], f16x8 (&al)[4], int hs) {
+          const int i = hs >> 1, t0 = (hs & 1) * 4;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int a = T[t0 + t][j3] + RG[i];
-          ah[t] = *reinterpret_cast<const f16x8 *>(imgH + a);
-          al[t] = *reinterpret_cast<const f16x8 *>(imgL + a);
+          for (int t = 0; t < 4; ++t) {
+            const int a = T[t0 + t] + RG[i];
+            ah[t] = *reinterpret_cast<const f16x8 *>(imgH + a);
+            al[t] = *reinterpret_cast<const f16x8 *>(imgL + a);
+          }
+        };
+        auto mult = [&](const f16x8 (&ah)[4], const f16x8 (&al)[4], int hs) {
+          const int i = hs >> 1, t0 = (hs & 1) * 4;
+#pragma unroll
+          for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t0 + t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[i][n], acc[t0 + t][n], 0, 0, 0);
+#pragma unroll
+          for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t0 + t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[i][n], acc[t0 + t][n], 0, 0, 0);
+#pragma unroll
+          for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t0 + t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[i][n], acc[t0 + t][n], 0, 0, 0);
+        };
+        if (!(A.dbg & 256)) {     // dbg 256: timing ablation, no MFMA loop
+          fetch(ahA, alA, 0);
+#pragma unroll
+          for (int hs = 0; hs < 14; hs += 2) {
+            fetch(ahB, alB, hs + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mult(ahA, alA, hs);
+            __builtin_amdgcn_sched_barrier(0);
+            if (hs + 2 < 14) fetch(ahA, alA, hs + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mult(ahB, alB, hs + 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
-      };
-      auto mult = [&](const f16x8 (&ah)[4], const f16x8 (&al)[4], int hs) {
-        const int sl = hs >> 1, t0 = (hs & 1) * 4;
+        lds_barrier();            // B1: this image is consumed; the mover is done with the previous logits and the next image
+        // pt[channel][unit], unit = 16*mt + 4g + r.  Round 0: column tile N0 <- my partial
+        {
+          const int co = (N0 << 4) + (lane & 15);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[sl], acc[t0 + t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[sl], acc[t0 + t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[sl], acc[t0 + t], 0, 0, 0);
-      };
-      if (!(A.dbg & 256)) {     // dbg 256: timing ablation, no MFMA loop
-        fetch(ahA, alA, 0);
-#pragma unroll
-        for (int hs = 0; hs < 2 * NS; hs += 2) {
-          fetch(ahB, alB, hs + 1);
-          __builtin_amdgcn_sched_barrier(0);
-          mult(ahA, alA, hs);
-          __builtin_amdgcn_sched_barrier(0);
-          if (hs + 2 < 2 * NS) fetch(ahA, alA, hs + 2);
-          __builtin_amdgcn_sched_barrier(0);
-          mult(ahB, alB, hs + 1);
-          __builtin_amdgcn_sched_barrier(0);
+          for (int mt = 0; mt < 8; ++mt)
+            if (co < C) *reinterpret_cast<f32x4 *>(pt + co * PTS + (mt << 4) + (g << 2)) = acc[mt][N0];
         }
-      }
-      lds_barrier();            // B1: this image is consumed; the mover is done with the previous logits and the next image
-      // logits (+bias) -> pt[channel][unit]: unit = 16*mt + 4g + r
+        lds_barrier();            // Bx
+        {
+          const int co = (N1 << 4) + (lane & 15);
 #pragma unroll
-      for (int mt = 0; mt < 8; ++mt) {
-        f32x4 v = acc[mt];
+          for (int mt = 0; mt < 8; ++mt)
+            if (co < C) {
+              f32x4 *q = reinterpret_cast<f32x4 *>(pt + co * PTS + (mt << 4) + (g << 2));
+              f32x4 v = *q;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = v[r] * kInvWScale + bv;      // the weights were packed scaled by 2^10
-        if (co < C) *reinterpret_cast<f32x4 *>(pt + co * UNITS + (mt << 4) + (g << 2)) = v;
+              for (int r = 0; r < 4; ++r) v[r] += acc[mt][N1][r];
+              *q = v;
+            }
+        }
+        lds_barrier();            // By
+        {
+#pragma unroll
+          for (int mt = 0; mt < 8; ++mt)
+            if (co2 < C) {
+              f32x4 *q = reinterpret_cast<f32x4 *>(pt + co2 * PTS + (mt << 4) + (g << 2));
+              f32x4 v = *q;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = (v[r] + acc[mt][N2][r]) * kInvWScale + bv2;     // weights were packed scaled by 2^10
+              *q = v;
+            }
+        }
+        lds_barrier();            // B2: logits complete
       }
-      lds_barrier();            // B2: logits complete
-    }
+    };
+    if (wave == 0) body(std::integral_constant<int, 0>{});
+    else if (wave == 1) body(std::integral_constant<int, 1>{});
+    else body(std::integral_constant<int, 2>{});
     return;
   }
 
@@ -305,7 +351,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       const float2 xv = xpre[pass];
       RegCol<float, C> a;
 #pragma unroll
-      for (int c = 0; c < C; ++c) a[c] = pt[c * UNITS + u];
+      for (int c = 0; c < C; ++c) a[c] = pt[c * PTS + u];
       float val, logd;
       rqs_site<float, M, FUSE == 2>(a, A.P, offp ? xv.y : xv.x, val, logd);
       float2 ov;
@@ -378,6 +424,8 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       if (pre && !(A.dbg & 64)) issue_item(n2b, n2o);
     }
     lds_barrier();                              // B1
+    lds_barrier();                              // Bx  (the compute waves' reduction rounds)
+    lds_barrier();                              // By
     pb = cb;
     cb = n1b;
     n1b = n2b;
