@@ -46,12 +46,13 @@ __host__ __device__ constexpr int rowidx(int r) { return ((r / 9) * H1 + (r / 3)
 // rows 4i .. 4i+3 (row 27 is padding: zero weights).  Same j3 for the four k-groups => same parity sub-image.
 constexpr int NS = 21;
 constexpr int UNITS = 128;                                // active sites per box
-constexpr float kInvWScale = 1.0f / 1024.0f;              // normflow__amd/_hip.py: SPLIT16_WEIGHT_SCALE
+constexpr float kWScale = 1024.0f, kInvWScale = 1.0f / 1024.0f;      // normflow__amd/_hip.py: SPLIT16_WEIGHT_SCALE
 constexpr int C = 46, M = 16;
 constexpr int PTS = UNITS + 4;                            // row stride of the logit scratch in floats: +4 spreads the 16 channels a
                                                           // wave writes at once over the banks (stride 128 put them all on one)
 constexpr int PT = C * PTS * 4;                           // bytes of the logit scratch
 constexpr int LDS_BYTES = 4 * IMG + PT;
+static_assert(2 * PT <= 2 * IMG, "two planes of partial sums must fit a consumed image");
 static_assert(LDS_BYTES <= 160 * 1024, "two image pairs and the logit scratch must fit the CU's LDS");
 
 __host__ __device__ constexpr int rowoff(int r) {         // halo-site offset of kernel row r = (j0, j1, j2)
@@ -59,11 +60,24 @@ __host__ __device__ constexpr int rowoff(int r) {         // halo-site offset of
 }
 }  // namespace h
 
+#ifndef NF_H_ABL
+#define NF_H_ABL 0      // timing ablations of the compute waves (tools only): 1 no fragment reads, 2 no reduction
+#endif
+
+typedef __attribute__((address_space(3))) float lds_f;
+
+template <int LO, int HI, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (LO < HI) {
+    f(std::integral_constant<int, LO>{});
+    static_for<LO + 1, HI>(f);
+  }
+}
+
 template <int FUSE>
 __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   using namespace h;
   extern __shared__ __align__(16) unsigned char smem_h[];
-  float *pt = reinterpret_cast<float *>(smem_h + 4 * IMG);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4;
@@ -107,134 +121,170 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     // Wave w multiplies the 7 slices of tap j3 = w (kernel rows 4i..4i+3, i = 0..6) into ALL three column tiles of all 8
     // site tiles: 36 MFMAs per 8 fragment reads and no fragment read by two waves (with one column tile per wave the
     // three waves read the same 1 MB per item and the LDS pipe, not the matrix pipe, set the pace).  The three partial
-    // sums meet in the logit scratch in three rounds, every wave working on a different column tile in each round:
-    // round 0 writes, rounds 1 and 2 add (fixed order per column tile: deterministic).
-    auto body = [&](auto WC) {
-      constexpr int W = decltype(WC)::value;                  // = j3
-      f16x8 bh[7][3], bl[7][3];
-      {
-        const f16x8 *__restrict__ wsp = static_cast<const f16x8 *>(A.wfrag) + lane;
+    // sums meet in the logit scratch in three rounds, every wave working on a different column tile in each round
+    // (round 0 stores, rounds 1 and 2 add in the LDS itself; fixed order per column tile: deterministic).
+    // Column SLOT k of wave w is column tile (w + k) % 3: the code is the same for the three waves, only data differ.
+    const int W = wave;
+    f16x8 bh[7][3], bl[7][3];
+    {
+      const f16x8 *__restrict__ wsp = static_cast<const f16x8 *>(A.wfrag) + lane;
 #pragma unroll
-        for (int i = 0; i < 7; ++i)
-#pragma unroll
-          for (int t = 0; t < 3; ++t) {
-            bh[i][t] = wsp[((t * NS + 7 * W + i) * 2) * 64];
-            bl[i][t] = wsp[((t * NS + 7 * W + i) * 2 + 1) * 64];
-          }
-      }
-      // byte offset of this lane's A read = T[site tile] + RG[i]: T places the lane's site (box row mt: z0 = mt>>2,
-      // z1 = (mt>>1)&1, z2 = mt&1; halo index 2p + parity + j3) in its parity sub-image, RG adds the halo rows of kernel
-      // row 4i + g.  Box extents are even, so the parity of a box row does not depend on the box.
-      int T[8], RG[7];
-      {
-        const int p = lane & 15;
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-          const int z0 = mt >> 2, z1 = (mt >> 1) & 1, z2 = mt & 1;
-          const int par = (A.parity + z0 + z1 + z2) & 1;
-          const int r0 = (z0 * H1 + z1) * H2 + z2;
-          const int z3 = 2 * p + par + W;
-          T[mt] = (z3 & 1) * SUB + (r0 * 17 + (z3 >> 1)) * 16;
-        }
+      for (int k = 0; k < 3; ++k) {
+        const int t = (W + k) % 3;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
-          const int r = 4 * i + g;
-          const int rr = r < 27 ? r : 26;
-          RG[i] = (((rr / 9) * H1 + (rr / 3) % 3) * H2 + rr % 3) * ROWB;
+          bh[i][k] = wsp[((t * NS + 7 * W + i) * 2) * 64];
+          bl[i][k] = wsp[((t * NS + 7 * W + i) * 2 + 1) * 64];
         }
       }
-      // columns this wave handles in the three reduction rounds
-      constexpr int N0 = W, N1 = (W + 1) % 3, N2 = (W + 2) % 3;
-      const int co2 = (N2 << 4) + (lane & 15);
-      const float bv2 = (A.bias && co2 < A.cout) ? static_cast<const float *>(A.bias)[co2] : 0.f;
-      lds_barrier();            // P: the mover has staged the first image
-      for (int m = 0; m < n_my; ++m) {
-        const unsigned char *imgH = smem_h + (m & 1) * 2 * IMG;
-        const unsigned char *imgL = imgH + IMG;
-        f32x4 acc[8][3];
+    }
+    // byte offset of this lane's A read = T[site tile] + RG[i]: T places the lane's site (box row mt: z0 = mt>>2,
+    // z1 = (mt>>1)&1, z2 = mt&1; halo index 2p + parity + j3) in its parity sub-image, RG adds the halo rows of kernel
+    // row 4i + g.  Box extents are even, so the parity of a box row does not depend on the box.
+    int TP[2], RG[7];        // T[mt] = TP[(z0 + z1 + z2) & 1] + r0(mt) * ROWB, the second term a compile-time offset
+    {
+      const int p = lane & 15;
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-          for (int t = 0; t < 3; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // 14 half-slices (4 site tiles each), fragments read one half-slice ahead
-        f16x8 ahA[4], alA[4], ahB[4], alB[4];
-        auto fetch = [&](f16x8 (&ah)[4], f16x8 (&al)[4], int hs) {
-          const int i = hs >> 1, t0 = (hs & 1) * 4;
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int a = T[t0 + t] + RG[i];
-            ah[t] = *reinterpret_cast<const f16x8 *>(imgH + a);
-            al[t] = *reinterpret_cast<const f16x8 *>(imgL + a);
-          }
-        };
-        auto mult = [&](const f16x8 (&ah)[4], const f16x8 (&al)[4], int hs) {
-          const int i = hs >> 1, t0 = (hs & 1) * 4;
-#pragma unroll
-          for (int n = 0; n < 3; ++n)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t0 + t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[i][n], acc[t0 + t][n], 0, 0, 0);
-#pragma unroll
-          for (int n = 0; n < 3; ++n)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t0 + t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[i][n], acc[t0 + t][n], 0, 0, 0);
-#pragma unroll
-          for (int n = 0; n < 3; ++n)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t0 + t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[i][n], acc[t0 + t][n], 0, 0, 0);
-        };
-        if (!(A.dbg & 256)) {     // dbg 256: timing ablation, no MFMA loop
-          fetch(ahA, alA, 0);
-#pragma unroll
-          for (int hs = 0; hs < 14; hs += 2) {
-            fetch(ahB, alB, hs + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mult(ahA, alA, hs);
-            __builtin_amdgcn_sched_barrier(0);
-            if (hs + 2 < 14) fetch(ahA, alA, hs + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            mult(ahB, alB, hs + 1);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        lds_barrier();            // B1: this image is consumed; the mover is done with the previous logits and the next image
-        // pt[channel][unit], unit = 16*mt + 4g + r.  Round 0: column tile N0 <- my partial
-        {
-          const int co = (N0 << 4) + (lane & 15);
-#pragma unroll
-          for (int mt = 0; mt < 8; ++mt)
-            if (co < C) *reinterpret_cast<f32x4 *>(pt + co * PTS + (mt << 4) + (g << 2)) = acc[mt][N0];
-        }
-        lds_barrier();            // Bx
-        {
-          const int co = (N1 << 4) + (lane & 15);
-#pragma unroll
-          for (int mt = 0; mt < 8; ++mt)
-            if (co < C) {
-              f32x4 *q = reinterpret_cast<f32x4 *>(pt + co * PTS + (mt << 4) + (g << 2));
-              f32x4 v = *q;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] += acc[mt][N1][r];
-              *q = v;
-            }
-        }
-        lds_barrier();            // By
-        {
-#pragma unroll
-          for (int mt = 0; mt < 8; ++mt)
-            if (co2 < C) {
-              f32x4 *q = reinterpret_cast<f32x4 *>(pt + co2 * PTS + (mt << 4) + (g << 2));
-              f32x4 v = *q;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = (v[r] + acc[mt][N2][r]) * kInvWScale + bv2;     // weights were packed scaled by 2^10
-              *q = v;
-            }
-        }
-        lds_barrier();            // B2: logits complete
+      for (int e = 0; e < 2; ++e) {
+        const int z3 = 2 * p + ((A.parity + e) & 1) + W;
+        TP[e] = (z3 & 1) * SUB + (z3 >> 1) * 16;
       }
-    };
-    if (wave == 0) body(std::integral_constant<int, 0>{});
-    else if (wave == 1) body(std::integral_constant<int, 1>{});
-    else body(std::integral_constant<int, 2>{});
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int r = 4 * i + g;
+        const int rr = r < 27 ? r : 26;
+        RG[i] = (((rr / 9) * H1 + (rr / 3) % 3) * H2 + rr % 3) * ROWB;
+      }
+    }
+    // The three partial sums of a column tile are NOT added here: slot 0 goes to the logit scratch pt[channel][unit]
+    // (unit = 16 mt + 4g + r: a 16-byte store per site tile, conflict-free with the row stride PTS), slots 1 and 2 to two
+    // more planes of the same shape laid over the image the item has just consumed.  One round of stores straight from the
+    // accumulator registers, a barrier, then the 192 lanes add the planes up 16 bytes at a time ((slot 0 + slot 1) + slot 2:
+    // deterministic; VGPRs only -- reading accumulators back for the adds, or ds_add_f32 at ~170 cycles per instruction,
+    // cost far more) and leave the rescaled logits in pt.  Slot 0's accumulators start from the bias, scaled by 2^10 like
+    // the weights.
+    const int lds0 = int(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char *)smem_h));
+    int ptk[3];               // LDS byte address of this lane's 16 bytes in plane k, site tile 0 (planes 1, 2: relative to the image)
+    bool okk[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int co = (((W + k) % 3) << 4) + (lane & 15);
+      okk[k] = co < C;
+      ptk[k] = lds0 + ((okk[k] ? co : 0) * PTS + (g << 2)) * 4 + (k == 0 ? 4 * IMG : (k - 1) * PT);
+    }
+    f32x4 acc0;               // what slot 0 starts from
+    {
+      const int co = (W << 4) + (lane & 15);
+      const float b0 = (A.bias && co < C) ? static_cast<const float *>(A.bias)[co] * kWScale : 0.f;
+      acc0 = f32x4{b0, b0, b0, b0};
+    }
+    f32x4 acc[8][3];
+    f16x8 fa[2][2], fl[2][2];                    // fragments (hi, lo) of two quarter-slices (2 site tiles each), read one ahead
+#if NF_H_ABL & 1
+    fa[0][0] = fa[0][1] = fa[1][0] = fa[1][1] = fl[0][0] = fl[0][1] = fl[1][0] = fl[1][1] = bh[0][0];
+#endif
+    lds_barrier();            // P: the mover has staged the first image
+    for (int m = 0; m < n_my; ++m) {
+      const int ioff = (m & 1) * 2 * IMG;
+      const unsigned char *img[2] = {smem_h + ioff + TP[0], smem_h + ioff + TP[1]};
+      auto fetch = [&](auto QC) {
+        constexpr int qs = decltype(QC)::value;
+        constexpr int i = qs >> 2, t0 = (qs & 3) * 2, q = qs & 1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int mt = t0 + t;
+          const int z0 = mt >> 2, z1 = (mt >> 1) & 1, z2 = mt & 1;
+          const unsigned char *src = img[(z0 + z1 + z2) & 1] + RG[i] + ((z0 * H1 + z1) * H2 + z2) * ROWB;
+          fa[q][t] = *reinterpret_cast<const f16x8 *>(src);
+          fl[q][t] = *reinterpret_cast<const f16x8 *>(src + IMG);
+        }
+      };
+      auto mult = [&](auto QC) {
+        constexpr int qs = decltype(QC)::value;
+        constexpr int i = qs >> 2, t0 = (qs & 3) * 2, q = qs & 1;
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[t0 + t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[q][t], bh[i][n], acc[t0 + t][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[t0 + t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[q][t], bl[i][n], acc[t0 + t][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[t0 + t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[q][t], bh[i][n], acc[t0 + t][n], 0, 0, 0);
+      };
+      [[maybe_unused]] auto step = [&](auto QC) {                 // quarter-slice qs: read qs + 1, multiply qs (18 MFMAs)
+        constexpr int qs = decltype(QC)::value;
+        if constexpr (qs + 1 < 28 && !(NF_H_ABL & 1)) fetch(std::integral_constant<int, qs + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+#if NF_H_ABL & 1
+        asm volatile("" : "+v"(fa[qs & 1][0]), "+v"(fl[qs & 1][0]), "+v"(fa[qs & 1][1]), "+v"(fl[qs & 1][1]));
+#endif
+        mult(QC);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto store_slot = [&](auto KC) {
+        constexpr int k = decltype(KC)::value;
+        if (okk[k]) {
+          const int ad = ptk[k] + (k == 0 ? 0 : ioff);
+#pragma unroll
+          for (int mt = 0; mt < 8; ++mt) {
+            const f32x4 val = acc[mt][k];
+#if NF_H_ABL & 16
+            asm volatile("" ::"v"(ad), "a"(val));
+#else
+            asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ad), "a"(val), "n"(mt << 6) : "memory");
+#endif
+          }
+        }
+      };
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[mt][n] = n == 0 ? acc0 : f32x4{0.f, 0.f, 0.f, 0.f};
+#if !(NF_H_ABL & 32)
+      if constexpr (!(NF_H_ABL & 1)) fetch(std::integral_constant<int, 0>{});
+      static_for<0, 28>(step);
+#endif
+      asm volatile("s_nop 15\n\ts_nop 3");      // the LDS instructions below read accumulators the compiler does not know they read: let the last MFMA land
+      lds_barrier();            // B1: image m is consumed; the mover has read the sums of item m-1
+      store_slot(std::integral_constant<int, 0>{});
+      store_slot(std::integral_constant<int, 1>{});
+      store_slot(std::integral_constant<int, 2>{});
+      lds_barrier();            // B2: the partial sums of item m are in place
+      // the three planes -> logits in pt: 46 x 32 16-byte chunks over the 192 lanes, (slot 0 + slot 1) + slot 2, rescaled
+      if constexpr (!(NF_H_ABL & 64)) {
+        const lds_f *pl = (const lds_f *)(smem_h + ioff);
+        lds_f *ptl = (lds_f *)(smem_h + 4 * IMG);
+#pragma unroll
+        for (int j0 = 0; j0 < 8; j0 += 4) {
+          f32x4 s0[4], s1[4], s2[4];
+          int off[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int chunk = (W << 6) + lane + 192 * (j0 + j);
+            const int ch = chunk < C * 32 ? chunk : 0;           // the last few lanes of the last pass redo chunk 0: same values
+            off[j] = (ch >> 5) * PTS + ((ch & 31) << 2);
+            s0[j] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(ptl + off[j]);
+            s1[j] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(pl + off[j]);
+            s2[j] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(pl + C * PTS + off[j]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = ((s0[j][r] + s1[j][r]) + s2[j][r]) * kInvWScale;      // the weights were packed scaled by 2^10
+            const int chunk = (W << 6) + lane + 192 * (j0 + j);
+            if (chunk < C * 32) *reinterpret_cast<__attribute__((address_space(3))) f32x4 *>(ptl + off[j]) = v;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      lds_barrier();            // Bs: the logits of item m are in pt
+    }
     return;
   }
 
@@ -341,6 +391,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     for (int pass = 0; pass < 2; ++pass) xpre[pass] = reinterpret_cast<const float2 *>(A.xact)[pair_of(b, o, pass)];
   };
   auto epilogue = [&](int b, const int (&o)[4], int64_t pidx) {
+    const lds_f *ptl = (const lds_f *)(smem_h + 4 * IMG);
     double lacc = 0.0;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -351,7 +402,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       const float2 xv = xpre[pass];
       RegCol<float, C> a;
 #pragma unroll
-      for (int c = 0; c < C; ++c) a[c] = pt[c * PTS + u];
+      for (int c = 0; c < C; ++c) a[c] = ptl[c * PTS + u];
       float val, logd;
       rqs_site<float, M, FUSE == 2>(a, A.P, offp ? xv.y : xv.x, val, logd);
       float2 ov;
@@ -390,19 +441,26 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   const int d_main = ((xs + 1) & 1) * SUB + (rs * 17 + ((xs + 1) >> 1)) * 16;
   const bool edge = xs == 0 || xs == 31;
   const int d_edge = xs == 0 ? SUB + (rs * 17 + 16) * 16 : (rs * 17) * 16;      // site 0 -> halo index 33 (odd, entry 16); site 31 -> index 0
-  auto commit_item = [&](unsigned char *imgH) {
+  // in thirds: one between each pair of the period's barriers, so that no segment of the period is the mover's alone
+  auto commit_item = [&](unsigned char *imgH, int part) {
+    constexpr int NI = NROW / 2;
 #pragma unroll
-    for (int i = 0; i < NROW / 2; ++i) {
-      unsigned char *p0 = imgH + d_main + i * (2 * ROWB);
-      *reinterpret_cast<f16x8 *>(p0) = qh[i];
-      *reinterpret_cast<f16x8 *>(p0 + IMG) = ql[i];
-    }
-    if (edge) {
+    for (int k = 0; k < 3; ++k) {
+      if (part != k && part != 3) continue;
+      constexpr int lo[4] = {0, 11, 22, NI};
 #pragma unroll
-      for (int i = 0; i < NROW / 2; ++i) {
-        unsigned char *p1 = imgH + d_edge + i * (2 * ROWB);
-        *reinterpret_cast<f16x8 *>(p1) = qh[i];
-        *reinterpret_cast<f16x8 *>(p1 + IMG) = ql[i];
+      for (int i = lo[k]; i < lo[k + 1]; ++i) {
+        unsigned char *p0 = imgH + d_main + i * (2 * ROWB);
+        *reinterpret_cast<f16x8 *>(p0) = qh[i];
+        *reinterpret_cast<f16x8 *>(p0 + IMG) = ql[i];
+      }
+      if (edge) {
+#pragma unroll
+        for (int i = lo[k]; i < lo[k + 1]; ++i) {
+          unsigned char *p1 = imgH + d_edge + i * (2 * ROWB);
+          *reinterpret_cast<f16x8 *>(p1) = qh[i];
+          *reinterpret_cast<f16x8 *>(p1 + IMG) = ql[i];
+        }
       }
     }
   };
@@ -414,24 +472,23 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   for (int m = 0; m < n_my; ++m) {
     if (m > 0 && !(A.dbg & 128)) epilogue(pb, po, int64_t(vb) + int64_t(m - 1) * nb);     // dbg 128: timing ablation
     prefetch_x(cb, co4);                        // for the epilogue of item m, one iteration from now
+    // image m+1 goes where image m-1 and then the partial sums of item m-1 were: after the epilogue above
     if (m + 1 < n_my && !(A.dbg & 64)) {        // dbg 64: timing ablation
-      if (pre) { if (!(A.dbg & 512)) commit_item(smem_h + ((m + 1) & 1) * 2 * IMG); }     // dbg 512: timing ablation, loads only
+      if (pre) { if (!(A.dbg & 512)) commit_item(smem_h + ((m + 1) & 1) * 2 * IMG, 3); }     // dbg 512: timing ablation, loads only
       else stage(n1b, n1o, smem_h + ((m + 1) & 1) * 2 * IMG);
     }
     int n2b = n1b, n2o[4] = {n1o[0], n1o[1], n1o[2], n1o[3]};
-    if (m + 2 < n_my) {
-      advance(n2b, n2o);
-      if (pre && !(A.dbg & 64)) issue_item(n2b, n2o);
-    }
-    lds_barrier();                              // B1
-    lds_barrier();                              // Bx  (the compute waves' reduction rounds)
-    lds_barrier();                              // By
+    if (m + 2 < n_my) advance(n2b, n2o);
+    lds_barrier();                              // B1: image m is consumed, pt is free
+    // the loads of item m+2 go out while the compute waves store and add: this wave has nothing else to do until Bs
+    if (m + 2 < n_my && pre && !(A.dbg & 64)) issue_item(n2b, n2o);
     pb = cb;
     cb = n1b;
     n1b = n2b;
 #pragma unroll
     for (int mu = 0; mu < 4; ++mu) { po[mu] = co4[mu]; co4[mu] = n1o[mu]; n1o[mu] = n2o[mu]; }
-    lds_barrier();                              // B2: logits of item m are in pt
+    lds_barrier();                              // B2: the partial sums of item m are in pt and in image m
+    lds_barrier();                              // Bs: the compute waves have added them up: logits of item m in pt
   }
   epilogue(pb, po, int64_t(vb) + int64_t(n_my - 1) * nb);
 }

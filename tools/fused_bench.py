@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("NORMFLOW_AMD_KEEP_TORCH_DEFAULTS", "1")
 import torch
 from normflow__amd import _hip
+if os.environ.get('NF_LIB'):              # an ablation build of the library (tools/_build/)
+    _hip.LIB_PATH = os.environ['NF_LIB']
 DEV = torch.device("cuda:0")
 lat, m, slab = (32,) * 4, 16, int(os.environ.get("SLAB", 64))
 V = 32 ** 4
@@ -12,6 +14,8 @@ h = torch.tanh(torch.randn((slab, 8) + lat, device=DEV, generator=g))
 x = torch.randn(slab, V, device=DEV, generator=g)
 w = 0.1 * torch.randn((46, 8, 3, 3, 3, 3), device=DEV, generator=g)
 b = 0.1 * torch.randn(46, device=DEV, generator=g)
+if os.environ.get('ZERO') == '1':      # zero operands: same instruction stream, least switching power
+    h.zero_(); w.zero_()
 opts = _hip.make_rqs_opts(m, (-5.0, 5.0), (-5.0, 5.0), {'left': 'linear', 'right': 'linear'}, _hip.LAYOUT_PAIR)
 if os.environ.get("SPLITIN", "1") == "1":          # what the pipeline feeds the kernel: (B, V, 16) halfs, hi | lo per site
     hp = h.reshape(slab, 8, V).permute(0, 2, 1).contiguous()
