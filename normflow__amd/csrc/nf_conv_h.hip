@@ -31,16 +31,17 @@ namespace nf {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace h {
-constexpr int H0 = 4, H1 = 4, H2 = 4, H3 = 34;            // halo box of a 2x2x2x32 box under a 3^4 kernel
-constexpr int NSITE = H0 * H1 * H2 * H3;                  // 2176
+constexpr int H0 = 4, H1 = 4, H2 = 4;                     // halo rows of a 2x2x2x32 box under a 3^4 kernel; the box spans the fastest axis
+constexpr int L3 = 32;                                    // (periodic): its two halo sites are the row's own end sites -- by address, not by copy
 constexpr int NROW = H0 * H1 * H2;                        // 64 halo rows: one per lane of the loader wave
-constexpr int IMG = NSITE * 16;                           // bytes of one fp16 image (8 channels = 16 bytes per site)
-// An image is two sub-images [parity pi of the halo index z3][row][17 entries of 16 bytes]: the 16 lanes of a k-group of
-// an A fragment (v_mfma_f32_16x16x32_f16: k-group g = the 8 channels of ONE tap) read sites of one parity -- active
-// sites sit at stride 2 -- i.e. 16 consecutive entries = 256 contiguous bytes, no bank conflict.  (In plain site order
-// the same read strides 32 bytes: a 4-way conflict, measured 35 instead of ~18 cycles per MFMA.)
-constexpr int ROWB = 17 * 16;                             // bytes of a row in a sub-image
-constexpr int SUB = NROW * ROWB;                          // 17408 bytes (a half-bank-period skew between the two parities: no effect)
+// An image (8 channels = 16 bytes per site, hi or lo halves) is two sub-images [parity of the site x3][row][16 entries of
+// 16 bytes]: the 16 lanes of a k-group of an A fragment (v_mfma_f32_16x16x32_f16: k-group g = the 8 channels of ONE tap)
+// read sites x3 = 2p + c - 1 mod 32 of one parity, i.e. the 16 entries of a row, rotated: 256 contiguous bytes, no bank
+// conflict.  (In plain site order the same read strides 32 bytes: a 4-way conflict, measured 35 instead of ~18 cycles
+// per MFMA.)
+constexpr int ROWB = 16 * 16;                             // bytes of a row in a sub-image
+constexpr int SUB = NROW * ROWB;                          // 16384
+constexpr int IMG = 2 * SUB;                              // bytes of one fp16 image
 __host__ __device__ constexpr int rowidx(int r) { return ((r / 9) * H1 + (r / 3) % 3) * H2 + r % 3; }   // kernel row -> halo row step
 // K slices of 32 = (4 kernel rows) x (8 channels) at ONE tap j3 of the fastest axis: slice sl = 7*j3 + i holds kernel
 // rows 4i .. 4i+3 (row 27 is padding: zero weights).  Same j3 for the four k-groups => same parity sub-image.
@@ -55,9 +56,6 @@ constexpr int LDS_BYTES = 4 * IMG + PT;
 static_assert(2 * PT <= 2 * IMG, "two planes of partial sums must fit a consumed image");
 static_assert(LDS_BYTES <= 160 * 1024, "two image pairs and the logit scratch must fit the CU's LDS");
 
-__host__ __device__ constexpr int rowoff(int r) {         // halo-site offset of kernel row r = (j0, j1, j2)
-  return (((r / 9) * H1 + (r / 3) % 3) * H2 + r % 3) * H3;
-}
 }  // namespace h
 
 #ifndef NF_H_ABL
@@ -146,8 +144,8 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       const int p = lane & 15;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const int z3 = 2 * p + ((A.parity + e) & 1) + W;
-        TP[e] = (z3 & 1) * SUB + (z3 >> 1) * 16;
+        const int x3 = (2 * p + ((A.parity + e) & 1) + W - 1) & (L3 - 1);      // tap W of active site p, wrapped
+        TP[e] = (x3 & 1) * SUB + (x3 >> 1) * 16;
       }
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
@@ -306,16 +304,12 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   constexpr int PB = 4;                          // passes per batch, two batches in flight
   const int rs = lane >> 5, xs = lane & 31;
   const bool pre = (A.dbg & 0x10000) != 0;       // input already split (flag carried in the high bits of dbg)
-  auto put = [&](unsigned char *imgH, int row, int z3, const f16x8 &hi, const f16x8 &lo) {
-    const int d = (z3 & 1) * SUB + (row * 17 + (z3 >> 1)) * 16;
+  auto put = [&](unsigned char *imgH, int row, int x3, const f16x8 &hi, const f16x8 &lo) {
+    const int d = (x3 & 1) * SUB + row * ROWB + (x3 >> 1) * 16;
     *reinterpret_cast<f16x8 *>(imgH + d) = hi;
     *reinterpret_cast<f16x8 *>(imgH + IMG + d) = lo;
   };
-  auto put3 = [&](unsigned char *imgH, int row, const f16x8 &hi, const f16x8 &lo) {
-    put(imgH, row, xs + 1, hi, lo);
-    if (xs == 0) put(imgH, row, H3 - 1, hi, lo);            // periodic copies: site 0 -> right halo, site 31 -> left halo
-    if (xs == 31) put(imgH, row, 0, hi, lo);
-  };
+  auto put3 = [&](unsigned char *imgH, int row, const f16x8 &hi, const f16x8 &lo) { put(imgH, row, xs, hi, lo); };
   auto stage = [&](int b, const int (&o)[4], unsigned char *imgH) {
     const int myoff = row_offsets(o);
     if (pre) {
@@ -438,30 +432,13 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   };
   // lane-constant parts of the LDS addresses (row = 2i + rs): the main store of the lane's site and, on the two edge
   // lanes of a row, the periodic copy; per pass only an immediate row offset is added and ONE branch guards the copies
-  const int d_main = ((xs + 1) & 1) * SUB + (rs * 17 + ((xs + 1) >> 1)) * 16;
-  const bool edge = xs == 0 || xs == 31;
-  const int d_edge = xs == 0 ? SUB + (rs * 17 + 16) * 16 : (rs * 17) * 16;      // site 0 -> halo index 33 (odd, entry 16); site 31 -> index 0
-  // in thirds: one between each pair of the period's barriers, so that no segment of the period is the mover's alone
-  auto commit_item = [&](unsigned char *imgH, int part) {
-    constexpr int NI = NROW / 2;
+  const int d_main = (xs & 1) * SUB + rs * ROWB + (xs >> 1) * 16;
+  auto commit_item = [&](unsigned char *imgH) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      if (part != k && part != 3) continue;
-      constexpr int lo[4] = {0, 11, 22, NI};
-#pragma unroll
-      for (int i = lo[k]; i < lo[k + 1]; ++i) {
-        unsigned char *p0 = imgH + d_main + i * (2 * ROWB);
-        *reinterpret_cast<f16x8 *>(p0) = qh[i];
-        *reinterpret_cast<f16x8 *>(p0 + IMG) = ql[i];
-      }
-      if (edge) {
-#pragma unroll
-        for (int i = lo[k]; i < lo[k + 1]; ++i) {
-          unsigned char *p1 = imgH + d_edge + i * (2 * ROWB);
-          *reinterpret_cast<f16x8 *>(p1) = qh[i];
-          *reinterpret_cast<f16x8 *>(p1 + IMG) = ql[i];
-        }
-      }
+    for (int i = 0; i < NROW / 2; ++i) {
+      unsigned char *p0 = imgH + d_main + i * (2 * ROWB);
+      *reinterpret_cast<f16x8 *>(p0) = qh[i];
+      *reinterpret_cast<f16x8 *>(p0 + IMG) = ql[i];
     }
   };
   int n1b = cb, n1o[4] = {co4[0], co4[1], co4[2], co4[3]};      // item m + 1 (in registers when pre)
@@ -474,7 +451,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     prefetch_x(cb, co4);                        // for the epilogue of item m, one iteration from now
     // image m+1 goes where image m-1 and then the partial sums of item m-1 were: after the epilogue above
     if (m + 1 < n_my && !(A.dbg & 64)) {        // dbg 64: timing ablation
-      if (pre) { if (!(A.dbg & 512)) commit_item(smem_h + ((m + 1) & 1) * 2 * IMG, 3); }     // dbg 512: timing ablation, loads only
+      if (pre) { if (!(A.dbg & 512)) commit_item(smem_h + ((m + 1) & 1) * 2 * IMG); }     // dbg 512: timing ablation, loads only
       else stage(n1b, n1o, smem_h + ((m + 1) & 1) * 2 * IMG);
     }
     int n2b = n1b, n2o[4] = {n1o[0], n1o[1], n1o[2], n1o[3]};
