@@ -430,8 +430,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       ql[i] = *reinterpret_cast<const f16x8 *>(src + voff + 16u);
     }
   };
-  // lane-constant parts of the LDS addresses (row = 2i + rs): the main store of the lane's site and, on the two edge
-  // lanes of a row, the periodic copy; per pass only an immediate row offset is added and ONE branch guards the copies
+  // lane-constant part of the LDS address (row = 2i + rs); per pass only an immediate row offset is added
   const int d_main = (xs & 1) * SUB + rs * ROWB + (xs >> 1) * 16;
   auto commit_item = [&](unsigned char *imgH) {
 #pragma unroll
@@ -524,9 +523,9 @@ int launch_conv_h(const ConvArgs &A0, int64_t B, int64_t nboxes, int fuse, hipSt
 //   compute(m) | barrier | commit image(m+1), store item m, issue loads(m+2) | barrier.
 template <int BZ2>
 struct GeoG {
-  static constexpr int H1 = 4, H2 = BZ2 + 2, H3 = 34;
+  static constexpr int H1 = 4, H2 = BZ2 + 2;                // (the fastest axis is spanned and periodic: wrapped by address, no halo sites)
   static constexpr int NROW = 4 * H1 * H2;                  // halo rows
-  static constexpr int ROWB = 17 * 16;
+  static constexpr int ROWB = 16 * 16;
   static constexpr int SUB = NROW * ROWB + 128;             // parity sub-image (+ bank skew)
   static constexpr int IMG = 2 * SUB;                       // one fp16 image (hi or lo)
   static constexpr int NTILE = 4 * BZ2;                     // site tiles (= box rows of 16 pairs)
@@ -597,7 +596,8 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
   for (int mt = 0; mt < G::TPW; ++mt) {
     const int zr = G::TPW * wave + mt;
     const int r0 = ((zr / (2 * BZ2)) * G::H1 + (zr / BZ2) % 2) * G::H2 + zr % BZ2;
-    T[mt] = (g & 1) * G::SUB + (r0 * 17 + (lane & 15) + (g >> 1)) * 16;
+    const int x3 = (2 * (lane & 15) + g - 1) & 31;       // tap g of the site pair (2p, 2p+1): sites 2p-1 .. 2p+2, wrapped
+    T[mt] = (x3 & 1) * G::SUB + r0 * G::ROWB + (x3 >> 1) * 16;
   }
   // ---- staging: wave w copies halo rows RPW*w .. RPW*w + RPW - 1, two per pass, one interior site per lane
   const int rs = lane >> 5, xs = lane & 31;
@@ -622,26 +622,15 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
       ql[i] = *reinterpret_cast<const f16x8 *>(src + voff + 16u);
     }
   };
-  // lane-constant parts of the LDS addresses (row = RPW*wave + 2i + rs): main store and, on the two edge lanes of a row,
-  // the periodic copy; per pass an immediate row offset is added and one branch guards all the copies
+  // lane-constant part of the LDS address (row = RPW*wave + 2i + rs); per pass an immediate row offset is added
   const int rbase = G::RPW * wave + rs;
-  const int d_main = ((xs + 1) & 1) * G::SUB + (rbase * 17 + ((xs + 1) >> 1)) * 16;
-  const bool edge = xs == 0 || xs == 31;
-  const int d_edge = xs == 0 ? G::SUB + (rbase * 17 + 16) * 16 : (rbase * 17) * 16;
+  const int d_main = (xs & 1) * G::SUB + rbase * G::ROWB + (xs >> 1) * 16;
   auto commit_item = [&]() {
 #pragma unroll
     for (int i = 0; i < G::NPASS; ++i) {
       unsigned char *p0 = imgH + d_main + i * (2 * G::ROWB);
       *reinterpret_cast<f16x8 *>(p0) = qh[i];
       *reinterpret_cast<f16x8 *>(p0 + G::IMG) = ql[i];
-    }
-    if (edge) {
-#pragma unroll
-      for (int i = 0; i < G::NPASS; ++i) {
-        unsigned char *p1 = imgH + d_edge + i * (2 * G::ROWB);
-        *reinterpret_cast<f16x8 *>(p1) = qh[i];
-        *reinterpret_cast<f16x8 *>(p1 + G::IMG) = ql[i];
-      }
     }
   };
 
