@@ -1,7 +1,7 @@
 // nf_conv_h.hip -- K5h: the fused last ConvAct layer (8 -> 46 channels at the active sites + RQ-spline coupling)
 // with every fp32 product computed as THREE fp16 matrix-core products,
 //        a * w  ~=  a_hi*w_hi + a_hi*w_lo + a_lo*w_hi        (x_hi = fp16(x), x_lo = fp16(x - x_hi)),
-// accumulated in fp32 (v_mfma_f32_16x16x16_f16).  The dropped term a_lo*w_lo is 2^-22 relative; measured against the
+// accumulated in fp32 (v_mfma_f32_16x16x32_f16).  The dropped term a_lo*w_lo is 2^-22 relative; measured against the
 // fp64 definition the layer's error is ~1.7x that of an fp32 fmaf chain over the same 648 terms (rms 1.1e-6 vs 6.5e-7
 // on O(1) outputs), inside the 1e-5 budget -- and the fp16 pipe is 16x the fp32 one per product, so a product costs
 // 3/16 of an fp32 MFMA slot (tools/mfma_probe3.hip: 370-410 fp32-equivalent TFLOP/s where the fp32 loop tops out at ~130).
@@ -9,16 +9,17 @@
 // the hidden activations are tanh outputs) and the weights are finite fp16-range numbers (checked on the host side).
 //
 // Shape of the computation (weight-stationary; reference: src/nn/scalar/modules.py:120-145 + couplings_.py:178-200):
-//   * one persistent workgroup per CU, 4 waves.  Waves 0-2 each own one 16-column tile of the 46 logit channels and keep
-//     its B fragments -- hi and lo, 41 K-slices of 16 = (2 taps x 8 input channels) -- in 164 registers for the whole
-//     launch; per item (sample, 2x2x2x32 box -> 128 active sites = 8 site tiles) a wave issues 8 x 41 x 3 MFMAs and reads
-//     only A fragments from LDS.
+//   * one persistent workgroup per CU, 4 waves, items = (sample, 2x2x2x32 box -> 128 active sites = 8 site tiles).
+//   * K = 648 is cut into 21 slices of 32 = (4 kernel rows x 8 input channels) at one tap j3 of the fastest axis
+//     (v_mfma_f32_16x16x32_f16).  Wave w in {0, 1, 2} owns tap j3 = w: its 7 slices for ALL three 16-column tiles of the
+//     46 logit channels, B fragments (hi, lo) in 168 registers for the whole launch, 8 x 3 accumulators, 504 MFMAs per
+//     item -- 9 per A fragment pair, and no fragment is read by two waves.
+//   * the three partial sums of a column tile meet in LDS: stored straight from the accumulator registers into the logit
+//     scratch and two planes laid over the consumed image, then added up 16 bytes at a time by the 192 lanes.
 //   * wave 3 is the data mover: while the others multiply item m it (a) runs the RQ-spline epilogue of item m-1 on the
-//     logits the compute waves left in LDS (the logits never reach HBM) and (b) stages item m+1: 64 halo rows x 8
-//     channel planes -> split into hi/lo fp16 -> two channel-last LDS images of 16 bytes per site.  With the taps of a
-//     slice adjacent along the fastest axis and the active sites at stride 2, the 64 lanes of an A read cover 512
-//     CONTIGUOUS bytes (no bank conflicts); slices pairing the third taps of two kernel rows pay a 2-way conflict.
-//   * two barriers per item; LDS = 2 x (2 x 34 KB) tile images + 23 KB of logits = 159 KB.
+//     logits in LDS (they never reach HBM) and (b) stages item m+1 from the (hi, lo) fp16 pairs the previous layer wrote
+//     (or splits fp32 planes itself: the fallback) into two parity-split channel-last LDS images of 16 bytes per site.
+//   * three barriers per item; LDS = 2 x (2 x 32 KB) images + 24 KB of logits = 152 KB.
 #include <cstdio>
 #include <cstdlib>
 #include <hip/hip_runtime.h>
