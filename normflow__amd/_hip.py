@@ -643,10 +643,11 @@ def conv_layer(x, weight, bias, act=0, compact=False, parity=0):
     return _conv_launch(x, weight.detach(), None if bias is None else bias.detach(), act, compact, parity)
 
 
-def conv_rqs(h, weight, bias, x_active, log0, parity, opts, inverse, unit_input=False, lattice=None):
+def conv_rqs(h, weight, bias, x_active, log0, parity, opts, inverse, unit_input=False, lattice=None, out=None):
     """Fused last conv layer + RQ-spline coupling (nf_conv_rqs); inference only.
     h: (B, cin, *L) fp32 hidden activations, or -- with `lattice` given -- the (B, V, 16) fp16 (hi, lo) pairs a
-    previous conv_layer(..., compact=2) wrote; x_active: (B, V); returns (y (B, V), logJ (B))."""
+    previous conv_layer(..., compact=2) wrote; x_active: (B, V); returns (y (B, V), logJ (B)).  `out` = (y, logJ)
+    tensors to fill instead of new ones (contiguous slices of a caller's batch: no concatenation afterwards)."""
     _require_device(h, weight, bias, x_active, log0)
     lib = load()
     h, x_active = h.contiguous(), x_active.contiguous()
@@ -665,8 +666,15 @@ def conv_rqs(h, weight, bias, x_active, log0, parity, opts, inverse, unit_input=
         flags |= 2                                                           # NF_CONV_SPLIT16_INPUT
     wfrag = conv_weight_for_layer(weight.detach(), lat4, k4, cin, weight.shape[0], True, 1 | ((flags & 1) << 1), NF_F32)
     bias = None if bias is None else bias.detach().contiguous()
-    y = torch.empty_like(x_active)
-    logj = torch.empty(B, dtype=x_active.dtype, device=x_active.device)
+    if out is None:
+        y = torch.empty_like(x_active)
+        logj = torch.empty(B, dtype=x_active.dtype, device=x_active.device)
+    else:
+        y, logj = out
+        if (tuple(y.shape) != (B, V) or tuple(logj.shape) != (B,) or y.dtype != x_active.dtype or logj.dtype != x_active.dtype
+                or not y.is_contiguous() or not logj.is_contiguous()):
+            raise NormflowHipError("conv_rqs: `out` must be contiguous (B, V) and (B,) tensors of the input's dtype")
+        _require_device(y, logj)
     ws = _workspace(min(B, MAX_B), V, h.device)
     for b0 in range(0, B, MAX_B):
         b1 = min(B, b0 + MAX_B)

@@ -232,20 +232,18 @@ class RQSplineCoupling_(Coupling_):
         v = x_active.reshape(B, -1)
         l0 = _hip._log0_tensor(log0, v, B)
         hidden = max(net.conv_kwargs['hidden_sizes'] or [1])
-        vals, logs = [], []
+        v = v.contiguous()
+        val = torch.empty_like(v)               # the slabs write their rows in place: no concatenation
+        lj = torch.empty(B, dtype=v.dtype, device=v.device)
         for b0, b1 in self._slabs(B, hidden * v.shape[1] * 4, self.HIDDEN_SLAB_BYTES):
             got = net.hidden_and_last(self.preprocess_fz(x_frozen[b0:b1]))
             if got is None:
                 return None
             h, last, unit, split = got
             opts = _hip.make_rqs_opts((n_out + 2) // 3, self.xlim, self.ylim, self.extrap, _hip.LAYOUT_PAIR)
-            val, lj = _hip.conv_rqs(h, last.weight, last.bias, v[b0:b1], None if l0 is None else l0[b0:b1], a,
-                                    opts, inverse, unit_input=unit,
-                                    lattice=tuple(x_frozen.shape[1:]) if split else None)
-            vals.append(val)
-            logs.append(lj)
-        val = vals[0] if len(vals) == 1 else torch.cat(vals)
-        lj = logs[0] if len(logs) == 1 else torch.cat(logs)
+            _hip.conv_rqs(h, last.weight, last.bias, v[b0:b1], None if l0 is None else l0[b0:b1], a,
+                          opts, inverse, unit_input=unit, lattice=tuple(x_frozen.shape[1:]) if split else None,
+                          out=(val[b0:b1], lj[b0:b1]))
         return val.reshape(x_active.shape), lj
 
     def _atom(self, inverse, *, x_active, x_frozen, parity, net, log0=0):
