@@ -535,7 +535,7 @@ struct GeoG {
   static constexpr int CS = SITES + 8;                      // channel stride of the output transpose (floats)
   static constexpr int RPW = NROW / 4;                      // halo rows staged per wave
   static constexpr int NPASS = RPW / 2;                     // two rows per pass
-  static constexpr int LDS = 2 * IMG + 8 * CS * 4;
+  static constexpr int LDS = 2 * IMG + 2 * 8 * CS * 4;      // one image (hi, lo) + two output transposes (item m's is stored while item m+1 multiplies)
   static __host__ __device__ constexpr int rowidx(int r) { return ((r / 9) * H1 + (r / 3) % 3) * H2 + r % 3; }
 };
 
@@ -635,6 +635,25 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
     }
   };
 
+  // one site of an item's output: 8 channels (position t of the transpose) -> fp16 (hi, lo) -> 32 bytes
+  constexpr int NOUT = G::SITES / 256;                      // sites per thread
+  auto store_site = [&](const float (&v)[8], int b, const int (&o)[4], int t) {
+    const int zr = t >> 5, tp = t & 31;
+    const int x3 = 8 * ((tp >> 1) & 3) + 2 * (tp >> 3) + (tp & 1);          // the transpose's bank-conflict-free site order
+    f16x8 hi, lo;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const _Float16 hh = static_cast<_Float16>(v[c]);
+      hi[c] = hh;
+      lo[c] = static_cast<_Float16>(v[c] - static_cast<float>(hh));
+    }
+    const int x0 = o[0] + zr / (2 * BZ2), x1 = o[1] + (zr / BZ2) % 2, x2 = o[2] + zr % BZ2;
+    unsigned char *d = static_cast<unsigned char *>(A.out) +
+                       (int64_t(b) * A.V + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + x3) * 32;
+    *reinterpret_cast<f16x8 *>(d) = hi;
+    *reinterpret_cast<f16x8 *>(d + 16) = lo;
+  };
+  int pcb = 0, pco4[4] = {0, 0, 0, 0};                      // the previous item: its output is stored during this item's multiplications
   int cb, co4[4], n1b, n1o[4];
   decode(vb, cb, co4);
   issue_item(cb, co4);
@@ -651,42 +670,69 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
     f32x4 acc[G::TPW];
 #pragma unroll
     for (int mt = 0; mt < G::TPW; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // 27 slices (one per kernel row), A fragments read two slices ahead (three named buffers)
-    f16x8 aA[G::TPW][2], aB[G::TPW][2], aC[G::TPW][2];            // [tile][hi|lo]
-    auto fetch = [&](f16x8 (&a)[G::TPW][2], int r) {
-      const int off = G::rowidx(r) * G::ROWB;
+    // 27 slices (one per kernel row (j0, j1, j2)).  The wave's TPW site tiles are consecutive along axis 2 at one
+    // (z0, z1), so for a given (j0, j1) tile mt with tap j2 reads halo row mt + j2 of the same line: TPW + 2 row fragments
+    // serve 3 TPW (tile, j2) pairs -- each fragment is read from LDS once per (j0, j1), not once per use (halves the
+    // phase's LDS reads; it is bound by the matrix pipe after that).  Fragments of the next (j0, j1) are read one step
+    // (9 TPW MFMAs) ahead.
+    constexpr int NR = G::TPW + 2;
+    f16x8 fA[NR][2], fB[NR][2];                                   // [row][hi|lo]
+    auto fetch = [&](f16x8 (&a)[NR][2], int jj) {
+      const int off = ((jj / 3) * G::H1 + jj % 3) * G::H2 * G::ROWB;
 #pragma unroll
-      for (int mt = 0; mt < G::TPW; ++mt) {
-        a[mt][0] = *reinterpret_cast<const f16x8 *>(imgH + T[mt] + off);
-        a[mt][1] = *reinterpret_cast<const f16x8 *>(imgL + T[mt] + off);
+      for (int q = 0; q < NR; ++q) {
+        a[q][0] = *reinterpret_cast<const f16x8 *>(imgH + T[0] + off + q * G::ROWB);
+        a[q][1] = *reinterpret_cast<const f16x8 *>(imgL + T[0] + off + q * G::ROWB);
       }
     };
-    auto mult = [&](const f16x8 (&a)[G::TPW][2], int r) {
+    auto mult = [&](const f16x8 (&a)[NR][2], int jj) {
 #pragma unroll
-      for (int mt = 0; mt < G::TPW; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt][0], bh[r], acc[mt], 0, 0, 0);
+      for (int j2 = 0; j2 < 3; ++j2)
 #pragma unroll
-      for (int mt = 0; mt < G::TPW; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt][0], bl[r], acc[mt], 0, 0, 0);
+        for (int mt = 0; mt < G::TPW; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt + j2][0], bh[3 * jj + j2], acc[mt], 0, 0, 0);
 #pragma unroll
-      for (int mt = 0; mt < G::TPW; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt][1], bh[r], acc[mt], 0, 0, 0);
+      for (int j2 = 0; j2 < 3; ++j2)
+#pragma unroll
+        for (int mt = 0; mt < G::TPW; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt + j2][0], bl[3 * jj + j2], acc[mt], 0, 0, 0);
+#pragma unroll
+      for (int j2 = 0; j2 < 3; ++j2)
+#pragma unroll
+        for (int mt = 0; mt < G::TPW; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt + j2][1], bh[3 * jj + j2], acc[mt], 0, 0, 0);
+    };
+    // the output of item m-1 leaves while item m multiplies: its transpose (the other ot buffer) is read before a step's
+    // MFMAs, converted and stored after them
+    const float *otp = ot + ((m + 1) & 1) * (8 * G::CS);
+    const bool outp = m > 0 && !(A.dbg & 4);
+    float ov[8];
+    auto out_load = [&](int k) {
+      if (outp) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) ov[c] = otp[c * G::CS + threadIdx.x + 256 * k];
+      }
+    };
+    auto out_store = [&](int k) {
+      if (outp) store_site(ov, pcb, pco4, threadIdx.x + 256 * k);
     };
     if (!(A.dbg & 1)) {
-      fetch(aA, 0);
-      fetch(aB, 1);
+      fetch(fA, 0);
 #pragma unroll
-      for (int r = 0; r < 27; r += 3) {
-        fetch(aC, r + 2);
+      for (int jj = 0; jj < 9; jj += 2) {
+        if (jj + 1 < 9) fetch(fB, jj + 1);
+        if (jj / 2 < NOUT) out_load(jj / 2);
         __builtin_amdgcn_sched_barrier(0);
-        mult(aA, r);
+        mult(fA, jj);
         __builtin_amdgcn_sched_barrier(0);
-        if (r + 3 < 27) fetch(aA, r + 3);
-        __builtin_amdgcn_sched_barrier(0);
-        mult(aB, r + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (r + 4 < 27) fetch(aB, r + 4);
-        __builtin_amdgcn_sched_barrier(0);
-        mult(aC, r + 2);
-        __builtin_amdgcn_sched_barrier(0);
+        if (jj + 1 < 9) {
+          if (jj + 2 < 9) fetch(fA, jj + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          mult(fB, jj + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (jj / 2 < NOUT) out_store(jj / 2);
       }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NOUT; ++k) { out_load(k); out_store(k); }
     }
     // bias + activation -> ot[co][box row][x3]: rows of D = pairs 4g + r of the tile
     if (A.act == kActTanh) {          // one straight-line copy for the common activation (code size: see conv_c1_kernel)
@@ -701,46 +747,39 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
         for (int r = 0; r < 4; ++r) acc[mt][r] = activate(acc[mt][r] * kInvWScale + bv, kActSigmoid);
     }
     {
-      float *o0 = ot + co * G::CS + (G::TPW * wave) * 32 + 8 * g + shift;
+      // site 8g + 2r + shift of the tile's lattice row sits at position 8r + 2g + shift: with the channel stride CS = 8 mod 64
+      // the 64 lanes of a store (8 channels x 4 k-groups x 2 sites) then fall on 64 different banks
+      float *o0 = ot + (m & 1) * (8 * G::CS) + co * G::CS + (G::TPW * wave) * 32 + 2 * g + shift;
 #pragma unroll
       for (int mt = 0; mt < G::TPW; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o0[mt * 32 + 2 * r] = acc[mt][r];
+        for (int r = 0; r < 4; ++r) o0[mt * 32 + 8 * r] = acc[mt][r];
     }
-    lds_barrier();                  // B0: the image is consumed, ot is complete
-    // next item's image (loads issued one iteration ago), this item's output, the loads of the item after next
+    lds_barrier();                  // B0: the image is consumed, this item's ot is complete
+    // next item's image (loads issued one iteration ago), the loads of the item after next
     if (m + 1 < n_my && !(A.dbg & 2)) commit_item();
-    if (!(A.dbg & 4)) {
-      // SITES/256 sites per thread: 8 channels -> fp16 (hi, lo) -> 32 bytes
-#pragma unroll
-      for (int k = 0; k < G::SITES / 256; ++k) {
-        const int t = threadIdx.x + 256 * k;
-        const int zr = t >> 5, x3 = t & 31;
-        f16x8 hi, lo;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const float v = ot[c * G::CS + t];
-          const _Float16 hh = static_cast<_Float16>(v);
-          hi[c] = hh;
-          lo[c] = static_cast<_Float16>(v - static_cast<float>(hh));
-        }
-        const int x0 = co4[0] + zr / (2 * BZ2), x1 = co4[1] + (zr / BZ2) % 2, x2 = co4[2] + zr % BZ2;
-        unsigned char *d = static_cast<unsigned char *>(A.out) +
-                           (int64_t(cb) * A.V + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + x3) * 32;
-        *reinterpret_cast<f16x8 *>(d) = hi;
-        *reinterpret_cast<f16x8 *>(d + 16) = lo;
-      }
-    }
     int n2b = n1b, n2o[4] = {n1o[0], n1o[1], n1o[2], n1o[3]};
     if (m + 2 < n_my) {
       advance(n2b, n2o);
       if (!(A.dbg & 2)) issue_item(n2b, n2o);
     }
-    lds_barrier();                  // B1: the next image is complete, ot is free
+    lds_barrier();                  // B1: the next image is complete
+    pcb = cb;
     cb = n1b;
     n1b = n2b;
 #pragma unroll
-    for (int mu = 0; mu < 4; ++mu) { co4[mu] = n1o[mu]; n1o[mu] = n2o[mu]; }
+    for (int mu = 0; mu < 4; ++mu) { pco4[mu] = co4[mu]; co4[mu] = n1o[mu]; n1o[mu] = n2o[mu]; }
+  }
+  // the last item's output
+  if (!(A.dbg & 4)) {
+    const float *otp = ot + ((n_my - 1) & 1) * (8 * G::CS);
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) {
+      float ov[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) ov[c] = otp[c * G::CS + threadIdx.x + 256 * k];
+      store_site(ov, pcb, pco4, threadIdx.x + 256 * k);
+    }
   }
 }
 

@@ -11,6 +11,8 @@ g = torch.Generator(device=DEV).manual_seed(1)
 h16 = (torch.rand((slab, V, 16), device=DEV, generator=g) - 0.5).half()
 w = 0.1 * torch.randn((8, 8, 3, 3, 3, 3), device=DEV, generator=g)
 b = 0.1 * torch.randn(8, device=DEV, generator=g)
+if os.environ.get('ZERO') == '1':      # zero operands: same instruction stream, least switching power
+    h16.zero_(); w.zero_()
 def timeit(f, n=3):
     for _ in range(2): f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
