@@ -155,13 +155,14 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
         RG[i] = (((rr / 9) * H1 + (rr / 3) % 3) * H2 + rr % 3) * ROWB;
       }
     }
-    // The three partial sums of a column tile are NOT added here: slot 0 goes to the logit scratch pt[channel][unit]
-    // (unit = 16 mt + 4g + r: a 16-byte store per site tile, conflict-free with the row stride PTS), slots 1 and 2 to two
-    // more planes of the same shape laid over the image the item has just consumed.  One round of stores straight from the
-    // accumulator registers, a barrier, then the 192 lanes add the planes up 16 bytes at a time ((slot 0 + slot 1) + slot 2:
-    // deterministic; VGPRs only -- reading accumulators back for the adds, or ds_add_f32 at ~170 cycles per instruction,
-    // cost far more) and leave the rescaled logits in pt.  Slot 0's accumulators start from the bias, scaled by 2^10 like
-    // the weights.
+    // The three partial sums of a column tile: slot 0 (the wave's OWN column tile, w) stays in the accumulators; slots 1 and
+    // 2 are stored straight from the accumulator registers (inline asm: hipcc would copy them to VGPRs first) into two
+    // planes [channel][unit] laid over the image the item has just consumed (unit = 16 mt + 4g + r: a 16-byte store per
+    // site tile, conflict-free with the row stride PTS); one barrier; every wave then reads the two partials for its own
+    // tile, adds ((slot 0 + slot 1) + slot 2: deterministic), rescales and stores the logits in pt.  LDS atomics for the
+    // adds (ds_add_f32: ~170 cycles per instruction) and three read-modify-write rounds through pt both cost far more;
+    // what the rounds cost is LDS bytes, and this form moves the fewest.  Slot 0's accumulators start from the bias,
+    // scaled by 2^10 like the weights.
     const int lds0 = int(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char *)smem_h));
     int ptk[3];               // LDS byte address of this lane's 16 bytes in plane k, site tile 0 (planes 1, 2: relative to the image)
     bool okk[3];
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       okk[k] = co < C;
       ptk[k] = lds0 + ((okk[k] ? co : 0) * PTS + (g << 2)) * 4 + (k == 0 ? 4 * IMG : (k - 1) * PT);
     }
+    const int home = (((W << 4) + (lane & 15)) * PTS + (g << 2)) * 4;      // byte offset of this lane's unit quad (site tile 0) in a plane, own column tile
     f32x4 acc0;               // what slot 0 starts from
     {
       const int co = (W << 4) + (lane & 15);
@@ -248,38 +250,23 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       static_for<0, 28>(step);
 #endif
       asm volatile("s_nop 15\n\ts_nop 3");      // the LDS instructions below read accumulators the compiler does not know they read: let the last MFMA land
-      lds_barrier();            // B1: image m is consumed; the mover has read the sums of item m-1
-      store_slot(std::integral_constant<int, 0>{});
+      lds_barrier();            // B1: image m is consumed; the mover has read the logits of item m-1
       store_slot(std::integral_constant<int, 1>{});
       store_slot(std::integral_constant<int, 2>{});
-      lds_barrier();            // B2: the partial sums of item m are in place
-      // the three planes -> logits in pt: 46 x 32 16-byte chunks over the 192 lanes, (slot 0 + slot 1) + slot 2, rescaled
-      if constexpr (!(NF_H_ABL & 64)) {
-        const lds_f *pl = (const lds_f *)(smem_h + ioff);
-        lds_f *ptl = (lds_f *)(smem_h + 4 * IMG);
+      lds_barrier();            // B2: the partial sums of the other two waves for this wave's own column tile are in place
+      // own tile (slot 0, still in the accumulators) + slot 1 of the previous wave + slot 2 of the one before: logits -> pt
+      if (okk[0]) {
+        typedef __attribute__((address_space(3))) f32x4 lds_q;
+        const lds_f *pa = (const lds_f *)(smem_h + ioff + home);       // plane 1, this lane's channel and unit quad of site tile 0
+        lds_f *po = (lds_f *)(smem_h + 4 * IMG + home);
 #pragma unroll
-        for (int j0 = 0; j0 < 8; j0 += 4) {
-          f32x4 s0[4], s1[4], s2[4];
-          int off[4];
+        for (int mt = 0; mt < 8; ++mt) {
+          const f32x4 s1 = *(const lds_q *)(pa + (mt << 4));
+          const f32x4 s2 = *(const lds_q *)(pa + PT / 4 + (mt << 4));
+          f32x4 v;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int chunk = (W << 6) + lane + 192 * (j0 + j);
-            const int ch = chunk < C * 32 ? chunk : 0;           // the last few lanes of the last pass redo chunk 0: same values
-            off[j] = (ch >> 5) * PTS + ((ch & 31) << 2);
-            s0[j] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(ptl + off[j]);
-            s1[j] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(pl + off[j]);
-            s2[j] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(pl + C * PTS + off[j]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = ((s0[j][r] + s1[j][r]) + s2[j][r]) * kInvWScale;      // the weights were packed scaled by 2^10
-            const int chunk = (W << 6) + lane + 192 * (j0 + j);
-            if (chunk < C * 32) *reinterpret_cast<__attribute__((address_space(3))) f32x4 *>(ptl + off[j]) = v;
-          }
-          __builtin_amdgcn_sched_barrier(0);
+          for (int r = 0; r < 4; ++r) v[r] = ((acc[mt][0][r] + s1[r]) + s2[r]) * kInvWScale;      // the weights were packed scaled by 2^10
+          *(lds_q *)(po + (mt << 4)) = v;
         }
       }
       lds_barrier();            // Bs: the logits of item m are in pt
