@@ -436,14 +436,15 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   for (int m = 0; m < n_my; ++m) {
     if (m > 0 && !(A.dbg & 128)) epilogue(pb, po, int64_t(vb) + int64_t(m - 1) * nb);     // dbg 128: timing ablation
     prefetch_x(cb, co4);                        // for the epilogue of item m, one iteration from now
+    int n2b = n1b, n2o[4] = {n1o[0], n1o[1], n1o[2], n1o[3]};
+    if (m + 2 < n_my) advance(n2b, n2o);
     // image m+1 goes where image m-1 and then the partial sums of item m-1 were: after the epilogue above
     if (m + 1 < n_my && !(A.dbg & 64)) {        // dbg 64: timing ablation
       if (pre) { if (!(A.dbg & 512)) commit_item(smem_h + ((m + 1) & 1) * 2 * IMG); }     // dbg 512: timing ablation, loads only
       else stage(n1b, n1o, smem_h + ((m + 1) & 1) * 2 * IMG);
     }
-    int n2b = n1b, n2o[4] = {n1o[0], n1o[1], n1o[2], n1o[3]};
-    if (m + 2 < n_my) advance(n2b, n2o);
-    lds_barrier();                              // B1: image m is consumed, pt is free
+    lds_barrier();                              // B1: image m is consumed, pt is free (committing the next image after this
+                                                //     barrier instead, in the store/add window, was measured: +9 %)
     // the loads of item m+2 go out while the compute waves store and add: this wave has nothing else to do until Bs
     if (m + 2 < n_my && pre && !(A.dbg & 64)) issue_item(n2b, n2o);
     pb = cb;
