@@ -655,6 +655,12 @@ __global__ __launch_bounds__(kBlock, 2) void conv_c1_kernel(ConvArgs A) {
   issue_all(shA);                                            // item 1 -> set A (committed at the end of item 0)
   lds_barrier();
 
+#ifdef NF_C1_TIMING
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define NF_TICK(k) { const unsigned long long tn = __builtin_readcyclecounter(); tacc[k] += tn - tprev; tprev = tn; }
+#else
+#define NF_TICK(k)
+#endif
   auto do_item = [&](int m, f32x4 (&sh_issue)[4], const f32x4 (&sh_commit)[4]) {
     const T *cur = buf + (m % 3) * A.S;
     if (m + 2 < n_my) advance(b2, o2);
@@ -695,6 +701,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_c1_kernel(ConvArgs A) {
         }
       }
     }
+    NF_TICK(0)      // issue + MFMA loop
     // ---- epilogue: bias + activation -> ot[co][box row][x3] -> 16-byte row pieces
     // (the common activation gets its own straight-line copy: sixteen inlined runtime switches over every
     //  activation made the item body ~40 KB of code, and the kernel instruction-fetch bound)
@@ -717,8 +724,11 @@ __global__ __launch_bounds__(kBlock, 2) void conv_c1_kernel(ConvArgs A) {
         const int p3 = u & ((1 << lb3) - 1), zr = u >> lb3;
         ot[co * CS + zr * b3 + 2 * p3 + shift] = acc[mt][r];
       }
+    NF_TICK(1)      // tanh + ot writes
     commit_all(sh_commit, buf + ((m + 1) % 3) * A.S);        // item m + 1 (issued one item ago) -> its plane
+    NF_TICK(2)      // commit
     lds_barrier();                                         // ot complete; plane m + 1 complete
+    NF_TICK(3)      // barrier
     if (A.out_split16) {
       // the next layer consumes fp16 (hi, lo) pairs, channel-last, 32 bytes per site (nf_conv_h.hip)
       typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -763,7 +773,9 @@ __global__ __launch_bounds__(kBlock, 2) void conv_c1_kernel(ConvArgs A) {
           *reinterpret_cast<acc_t *>(out_b + int64_t(c) * A.V + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + x3) = v;
       }
     }
+    NF_TICK(4)      // output
     lds_barrier();                                         // ot is free again
+    NF_TICK(5)      // barrier
     cb = b1;
     b1 = b2;
 #pragma unroll
@@ -773,6 +785,11 @@ __global__ __launch_bounds__(kBlock, 2) void conv_c1_kernel(ConvArgs A) {
     do_item(m, shB, shA);
     if (m + 1 < n_my) do_item(m + 1, shA, shB);
   }
+#ifdef NF_C1_TIMING
+  if (blockIdx.x == 8 && threadIdx.x == 0 && n_my > 100)
+    printf("[c1 timing] items %d | cycles per item: mma %.0f  epilogue %.0f  commit %.0f  barrier %.0f  output %.0f  barrier %.0f\n", n_my,
+           double(tacc[0]) / n_my, double(tacc[1]) / n_my, double(tacc[2]) / n_my, double(tacc[3]) / n_my, double(tacc[4]) / n_my, double(tacc[5]) / n_my);
+#endif
 }
 
 template <int MT, int NROWS>

@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("NORMFLOW_AMD_KEEP_TORCH_DEFAULTS", "1")
 import torch
 from normflow__amd import _hip
+if os.environ.get('NF_LIB'):              # an ablation / instrumented build of the library (tools/_build/)
+    _hip.LIB_PATH = os.environ['NF_LIB']
 DEV = torch.device("cuda:0")
 lat, slab = (32,) * 4, int(os.environ.get("SLAB", 64))
 V = 32 ** 4
