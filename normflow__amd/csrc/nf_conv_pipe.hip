@@ -655,6 +655,35 @@ __global__ __launch_bounds__(kBlock, 2) void conv_c1_kernel(ConvArgs A) {
   issue_all(shA);                                            // item 1 -> set A (committed at the end of item 0)
   lds_barrier();
 
+  // split16 output (the bench's path): the transpose is double-buffered and item m-1 is converted and stored between
+  // the MFMA groups of item m
+  constexpr int NT = (2 * UNITS + kBlock - 1) / kBlock;     // sites per thread
+  const bool wov = A.out_split16 != 0;
+  int pcb = 0, pco4[4] = {0, 0, 0, 0};
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  auto store_site16 = [&](const float (&v)[8], int b, const int (&o)[4], int t) {
+    if (t >= 2 * UNITS) return;
+    int zr = t / b3;
+    const int x3 = o[3] + (t - zr * b3);
+    h8 hi, lo;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const _Float16 hh = static_cast<_Float16>(v[c]);
+      hi[c] = hh;
+      lo[c] = static_cast<_Float16>(v[c] - static_cast<float>(hh));
+    }
+    const int z2 = zr & (A.box[2] - 1);
+    zr >>= A.lbox[2];
+    const int z1 = zr & (A.box[1] - 1);
+    zr >>= A.lbox[1];
+    const int x0 = o[0] + zr, x1 = o[1] + z1, x2 = o[2] + z2;
+    if (x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2] && x3 < A.L[3]) {
+      unsigned char *d = static_cast<unsigned char *>(A.out) + int64_t(b) * A.V * 32 +
+                         (((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + x3) * 32;
+      *reinterpret_cast<h8 *>(d) = hi;
+      *reinterpret_cast<h8 *>(d + 16) = lo;
+    }
+  };
 #ifdef NF_C1_TIMING
   unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
 #define NF_TICK(k) { const unsigned long long tn = __builtin_readcyclecounter(); tacc[k] += tn - tprev; tprev = tn; }
@@ -686,10 +715,17 @@ __global__ __launch_bounds__(kBlock, 2) void conv_c1_kernel(ConvArgs A) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) acc[mt] = Mma<T>::mma(a[j][mt], wreg[3 * g3 + j], acc[mt]);
       };
+      const T *otp = ot + ((m + 1) & 1) * (8 * CS);            // item m - 1's transpose
+      const bool outp = wov && m > 0;
+      float ov[8];
       fetch(a0, 0);
 #pragma unroll
       for (int g3 = 0; g3 < NG3; g3 += 2) {
         if (g3 + 1 < NG3) fetch(a1, g3 + 1);
+        if (g3 / 2 < NT && outp) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) ov[c] = otp[c * CS + ((threadIdx.x + kBlock * (g3 / 2)) < 2 * UNITS ? threadIdx.x + kBlock * (g3 / 2) : 0)];
+        }
         __builtin_amdgcn_sched_barrier(0);
         mult(a0, g3);
         __builtin_amdgcn_sched_barrier(0);
@@ -699,6 +735,16 @@ __global__ __launch_bounds__(kBlock, 2) void conv_c1_kernel(ConvArgs A) {
           mult(a1, g3 + 1);
           __builtin_amdgcn_sched_barrier(0);
         }
+        if (g3 / 2 < NT && outp) store_site16(ov, pcb, pco4, threadIdx.x + kBlock * (g3 / 2));
+      }
+    } else if (wov && m > 0) {
+      const T *otp = ot + ((m + 1) & 1) * (8 * CS);
+      for (int k = 0; k < NT; ++k) {
+        float ov[8];
+        const int t = threadIdx.x + kBlock * k;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) ov[c] = otp[c * CS + (t < 2 * UNITS ? t : 0)];
+        store_site16(ov, pcb, pco4, t);
       }
     }
     NF_TICK(0)      // issue + MFMA loop
@@ -722,39 +768,15 @@ __global__ __launch_bounds__(kBlock, 2) void conv_c1_kernel(ConvArgs A) {
       for (int r = 0; r < 4; ++r) {
         const int u = ((wave * MT + mt) << 4) + (g << 2) + r;
         const int p3 = u & ((1 << lb3) - 1), zr = u >> lb3;
-        ot[co * CS + zr * b3 + 2 * p3 + shift] = acc[mt][r];
+        ot[(wov ? (m & 1) * (8 * CS) : 0) + co * CS + zr * b3 + 2 * p3 + shift] = acc[mt][r];
       }
     NF_TICK(1)      // tanh + ot writes
     commit_all(sh_commit, buf + ((m + 1) % 3) * A.S);        // item m + 1 (issued one item ago) -> its plane
     NF_TICK(2)      // commit
     lds_barrier();                                         // ot complete; plane m + 1 complete
     NF_TICK(3)      // barrier
-    if (A.out_split16) {
-      // the next layer consumes fp16 (hi, lo) pairs, channel-last, 32 bytes per site (nf_conv_h.hip)
-      typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-      unsigned char *ob = static_cast<unsigned char *>(A.out) + int64_t(cb) * A.V * 32;
-      for (int t = threadIdx.x; t < 2 * UNITS; t += kBlock) {
-        int zr = t / b3;
-        const int x3 = co4[3] + (t - zr * b3);
-        h8 hi, lo;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const float v = ot[c * CS + t];
-          const _Float16 hh = static_cast<_Float16>(v);
-          hi[c] = hh;
-          lo[c] = static_cast<_Float16>(v - static_cast<float>(hh));
-        }
-        const int z2 = zr & (A.box[2] - 1);
-        zr >>= A.lbox[2];
-        const int z1 = zr & (A.box[1] - 1);
-        zr >>= A.lbox[1];
-        const int x0 = co4[0] + zr, x1 = co4[1] + z1, x2 = co4[2] + z2;
-        if (x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2] && x3 < A.L[3]) {
-          unsigned char *d = ob + (((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + x3) * 32;
-          *reinterpret_cast<h8 *>(d) = hi;
-          *reinterpret_cast<h8 *>(d + 16) = lo;
-        }
-      }
+    if (wov) {
+      // (stored during the next item's MFMA groups; the last item's after the loop)
     } else {
       T *__restrict__ out_b = static_cast<T *>(A.out) + int64_t(cb) * A.cout * A.V;
       const int lq = lb3 - 1;
@@ -774,8 +796,11 @@ __global__ __launch_bounds__(kBlock, 2) void conv_c1_kernel(ConvArgs A) {
       }
     }
     NF_TICK(4)      // output
-    lds_barrier();                                         // ot is free again
+    if (!wov) lds_barrier();                               // ot is free again (split16: the other buffer is written next)
     NF_TICK(5)      // barrier
+    pcb = cb;
+#pragma unroll
+    for (int mu = 0; mu < 4; ++mu) pco4[mu] = co4[mu];
     cb = b1;
     b1 = b2;
 #pragma unroll
@@ -784,6 +809,16 @@ __global__ __launch_bounds__(kBlock, 2) void conv_c1_kernel(ConvArgs A) {
   for (int m = 0; m < n_my; m += 2) {
     do_item(m, shB, shA);
     if (m + 1 < n_my) do_item(m + 1, shA, shB);
+  }
+  if (wov) {                                                 // the last item's output
+    const T *otp = ot + ((n_my - 1) & 1) * (8 * CS);
+    for (int k = 0; k < NT; ++k) {
+      float ov[8];
+      const int t = threadIdx.x + kBlock * k;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) ov[c] = otp[c * CS + (t < 2 * UNITS ? t : 0)];
+      store_site16(ov, pcb, pco4, t);
+    }
   }
 #ifdef NF_C1_TIMING
   if (blockIdx.x == 8 && threadIdx.x == 0 && n_my > 100)
@@ -842,7 +877,8 @@ int launch_conv_c1(const ConvArgs &A0, int MT, int64_t B, int64_t nboxes, hipStr
   A.nitems = B * nboxes;
   A.nboxes = int(nboxes);
   if (A.nitems >= (int64_t(1) << 31) - 4096) return -2;
-  const size_t lds = (size_t(3) * A.S + size_t(8) * (2 * (kBlock / kWave) * MT * 16 + 8)) * sizeof(float);
+  // three input planes + the output transpose (two of them for the split16 output: item m-1 leaves while item m multiplies)
+  const size_t lds = (size_t(3) * A.S + size_t(A.out_split16 ? 2 : 1) * 8 * (2 * (kBlock / kWave) * MT * 16 + 8)) * sizeof(float);
   if (lds > 160 * 1024) return 0;
   if (MT == 4) return nrows == 27 ? launch_c1<4, 27>(A, lds, stream) : (nrows == 9 ? launch_c1<4, 9>(A, lds, stream) : launch_c1<4, 3>(A, lds, stream));
   return nrows == 27 ? launch_c1<2, 27>(A, lds, stream) : (nrows == 9 ? launch_c1<2, 9>(A, lds, stream) : launch_c1<2, 3>(A, lds, stream));
