@@ -663,6 +663,12 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
     issue_item(n1b, n1o);
   }
   lds_barrier();
+#ifdef NF_G_TIMING      // diagnostic build: cycle counters around the phases of an item (tools/g_bench.py prints them)
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define NF_GTICK(k) { const unsigned long long tn = __builtin_readcyclecounter(); tacc[k] += tn - tprev; tprev = tn; }
+#else
+#define NF_GTICK(k)
+#endif
   for (int m = 0; m < n_my; ++m) {
     f32x4 acc[G::TPW];
 #pragma unroll
@@ -731,6 +737,7 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
 #pragma unroll
       for (int k = 0; k < NOUT; ++k) { out_load(k); out_store(k); }
     }
+    NF_GTICK(0)     // MFMA steps (+ the previous item's output)
     // bias + activation -> ot[co][box row][x3]: rows of D = pairs 4g + r of the tile
     if (A.act == kActTanh) {          // one straight-line copy for the common activation (code size: see conv_c1_kernel)
 #pragma unroll
@@ -752,21 +759,32 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) o0[mt * 32 + 8 * r] = acc[mt][r];
     }
+    NF_GTICK(1)     // tanh + transpose stores
     lds_barrier();                  // B0: the image is consumed, this item's ot is complete
+    NF_GTICK(2)     // barrier
     // next item's image (loads issued one iteration ago), the loads of the item after next
     if (m + 1 < n_my && !(A.dbg & 2)) commit_item();
+    NF_GTICK(3)     // commit
     int n2b = n1b, n2o[4] = {n1o[0], n1o[1], n1o[2], n1o[3]};
     if (m + 2 < n_my) {
       advance(n2b, n2o);
       if (!(A.dbg & 2)) issue_item(n2b, n2o);
     }
+    NF_GTICK(4)     // issue: 96 KB per item through the CU's 64 B/clk load path -- 1.5 k cycles at best; moved behind the MFMA
+                    // steps the same cycles show up there (the waves issue in order)
     lds_barrier();                  // B1: the next image is complete
+    NF_GTICK(5)     // barrier
     pcb = cb;
     cb = n1b;
     n1b = n2b;
 #pragma unroll
     for (int mu = 0; mu < 4; ++mu) { pco4[mu] = co4[mu]; co4[mu] = n1o[mu]; n1o[mu] = n2o[mu]; }
   }
+#ifdef NF_G_TIMING
+  if (blockIdx.x == 8 && threadIdx.x == 0 && n_my > 100)
+    printf("[g timing] items %d | cycles per item: mfma %.0f  epilogue %.0f  barrier %.0f  commit %.0f  issue %.0f  barrier %.0f\n", n_my,
+           double(tacc[0]) / n_my, double(tacc[1]) / n_my, double(tacc[2]) / n_my, double(tacc[3]) / n_my, double(tacc[4]) / n_my, double(tacc[5]) / n_my);
+#endif
   // the last item's output
   if (!(A.dbg & 4)) {
     const float *otp = ot + ((n_my - 1) & 1) * (8 * G::CS);
