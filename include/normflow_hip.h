@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NF_VERSION 100 /* 0.1.0 */
+#define NF_VERSION 200 /* 0.2.0 */
 
 /* NF_F16 (nf_rqs_fwd / nf_rqs_inv only, knots_len 4/8/16): x, params and y are IEEE half, the arithmetic is fp32 and
  * log0 / logj are fp32 ("fp16 params / fp32 log-det accumulate", BASELINE config 5). */
@@ -77,6 +77,19 @@ typedef struct nf_strides {
 
 int nf_version(void);
 const char *nf_last_error_string(void);
+
+/* Process-wide kernel-selection options.  They choose between kernels that compute the SAME layer (results within the
+ * tolerances stated per kernel); none of them skips work.  The library never reads the environment in a product build
+ * (timing ablations and clock stamps exist only in `make DIAG=1` builds, which define NF_DIAG).
+ *   NF_OPT_SPLIT16 (default 1): tanh / logistic ConvAct stacks may run the split-fp16 kernels (nf_conv_h.hip: every fp32
+ *                  product as three fp16 matrix-core products, fp32 accumulation); 0 = exact fp32 MFMA products everywhere
+ *                  (nf_conv_weight_layout / nf_conv_split16_supported answer accordingly);
+ *   NF_OPT_PIPE    (default 1): eligible fp32 layers run the persistent, staging-overlapped kernels (nf_conv_pipe.hip);
+ *                  0 = one box per workgroup (nf_conv.hip).
+ * nf_set_option returns the previous value (>= 0) or NF_EINVAL; set options before launching, not concurrently with calls. */
+enum nf_option { NF_OPT_SPLIT16 = 0, NF_OPT_PIPE = 1, NF_OPT_COUNT_ = 2 };
+int nf_set_option(int which, int value);
+int nf_get_option(int which);
 
 /* Bytes of scratch needed by any coupling / distconv call on a (B, V) problem. */
 size_t nf_workspace_bytes(int64_t B, int64_t V);

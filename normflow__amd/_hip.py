@@ -19,6 +19,9 @@ LAYOUT_FULL, LAYOUT_PAIR = 0, 1
 EXTRAP = {None: 0, 'none': 0, 'linear': 1, 'anti': 2, 'anti-periodic': 2}
 
 
+OPT_SPLIT16, OPT_PIPE = 0, 1
+
+
 class NormflowHipError(RuntimeError):
     pass
 
@@ -40,6 +43,8 @@ _VJP_ARGS = [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, C.POINTER(RqsOpts), C.POINT
 PROTOTYPES = {
     "nf_version": (C.c_int, []),
     "nf_last_error_string": (C.c_char_p, []),
+    "nf_set_option": (C.c_int, [C.c_int, C.c_int]),
+    "nf_get_option": (C.c_int, [C.c_int]),
     "nf_workspace_bytes": (_SZ, [_I64, _I64]),
     "nf_rqs_fwd": (_I, _MAP_ARGS),
     "nf_rqs_inv": (_I, _MAP_ARGS),
@@ -96,6 +101,28 @@ def load():
     return _lib
 
 
+class options:
+    """Context manager / setter for the library's kernel-selection options (include/normflow_hip.h, nf_set_option):
+    `with _hip.options(split16=False): ...` runs the block with exact fp32 MFMA products everywhere."""
+    _CODES = {"split16": OPT_SPLIT16, "pipe": OPT_PIPE}
+
+    def __init__(self, **kw):
+        self._new = {self._CODES[k]: int(bool(v)) for k, v in kw.items()}
+        self._old = {}
+
+    def __enter__(self):
+        lib = load()
+        for code, val in self._new.items():
+            self._old[code] = lib.nf_set_option(code, val)
+        return self
+
+    def __exit__(self, *exc):
+        lib = load()
+        for code, val in self._old.items():
+            lib.nf_set_option(code, val)
+        return False
+
+
 def _check(rc, what):
     if rc != 0:
         msg = load().nf_last_error_string().decode("utf-8", "replace")
@@ -124,18 +151,12 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-_ws_cache = {}
-
-
 def _workspace(B, V, device):
-    """Per-device scratch buffer for the per-workgroup log-det partials (grown on demand)."""
+    """Scratch buffer for the per-workgroup log-det partials of ONE call, taken from torch's caching allocator:
+    stream-aware (two streams never share partials) and graph-pool safe (a buffer captured into a HIP graph belongs
+    to the graph's private pool and is never handed out again while the graph lives)."""
     need = load().nf_workspace_bytes(B, V)
-    key = (device.type, device.index)
-    buf = _ws_cache.get(key)
-    if buf is None or buf.numel() < need:
-        buf = torch.empty(max(need, 1 << 22), dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
-    return buf
+    return torch.empty(max(int(need), 256), dtype=torch.uint8, device=device)
 
 
 def _ptr(t):
@@ -247,21 +268,29 @@ class MultiRQSCouplingFn(torch.autograd.Function):
         _require_device(v, params, mask, log0)
         B, ns, V = v.shape
         v, params = v.contiguous(), params.contiguous()
+        if params.dtype != v.dtype:        # the channels are addressed by byte offsets: a silent reinterpretation otherwise
+            raise TypeError(f"field is {v.dtype} but net output is {params.dtype}")
+        if log0 is not None and log0.dtype != v.dtype:
+            raise TypeError(f"log0 must be {v.dtype} for a {v.dtype} field")
         Ctot, Vp = params.shape[1], params.shape[2]
         Cs = Ctot // ns
         out = torch.empty_like(v)
         lib = load()
         fn = lib.nf_rqs_inv if inverse else lib.nf_rqs_fwd
-        ws = _workspace(B, V, v.device)
+        ws = _workspace(min(B, MAX_B), V, v.device)
         esz = v.element_size()
         st = Strides(ns * V, ns * V, Ctot * Vp)
         logj = log0
         for i, opts in enumerate(opts_list):
             nxt = torch.empty(B, dtype=v.dtype, device=v.device)
-            _check(fn(C.c_void_p(v.data_ptr() + i * V * esz), C.c_void_p(params.data_ptr() + i * Cs * Vp * esz),
-                      _ptr(mask), _ptr(logj), C.c_void_p(out.data_ptr() + i * V * esz), _ptr(nxt), B, V,
-                      C.byref(opts), C.byref(st), _ptr(ws), ws.numel(), _dtype_code(v), _stream()),
-                   "nf_rqs (multi)")
+            for b0 in range(0, B, MAX_B):       # the batch is the grid's y extent
+                b1 = min(B, b0 + MAX_B)
+                l0 = logj[b0:b1] if logj is not None else None
+                _check(fn(C.c_void_p(v[b0:b1].data_ptr() + i * V * esz),
+                          C.c_void_p(params[b0:b1].data_ptr() + i * Cs * Vp * esz), _ptr(mask), _ptr(l0),
+                          C.c_void_p(out[b0:b1].data_ptr() + i * V * esz), _ptr(nxt[b0:b1]), b1 - b0, V,
+                          C.byref(opts), C.byref(st), _ptr(ws), ws.numel(), _dtype_code(v), _stream()),
+                       "nf_rqs (multi)")
             logj = nxt
         ctx.save_for_backward(out if inverse else v, params, mask)
         ctx.opts_list, ctx.inverse, ctx.has_log0 = opts_list, inverse, log0 is not None
@@ -281,10 +310,12 @@ class MultiRQSCouplingFn(torch.autograd.Function):
         st = Strides(ns * V, ns * V, Ctot * Vp)
         for i, opts in enumerate(ctx.opts_list):
             xo, po = i * V * esz, i * Cs * Vp * esz
-            _check(fn(C.c_void_p(x.data_ptr() + xo), C.c_void_p(params.data_ptr() + po), _ptr(mask),
-                      C.c_void_p(gout.data_ptr() + xo), _ptr(glogj), C.c_void_p(gin.data_ptr() + xo),
-                      C.c_void_p(gpar.data_ptr() + po), B, V, C.byref(opts), C.byref(st), _dtype_code(x),
-                      _stream()), "nf_rqs_vjp (multi)")
+            for b0 in range(0, B, MAX_B):
+                b1 = min(B, b0 + MAX_B)
+                _check(fn(C.c_void_p(x[b0:b1].data_ptr() + xo), C.c_void_p(params[b0:b1].data_ptr() + po), _ptr(mask),
+                          C.c_void_p(gout[b0:b1].data_ptr() + xo), _ptr(glogj[b0:b1]),
+                          C.c_void_p(gin[b0:b1].data_ptr() + xo), C.c_void_p(gpar[b0:b1].data_ptr() + po), b1 - b0, V,
+                          C.byref(opts), C.byref(st), _dtype_code(x), _stream()), "nf_rqs_vjp (multi)")
         return gin, gpar, (glogj if ctx.has_log0 else None), None, None, None
 
 
@@ -473,6 +504,25 @@ def pack_conv_weight_split16_two_site(w):
     return out.contiguous()
 
 
+def to_split16(h):
+    """(B, 8, *L) fp32 hidden activations (|h| <= 1) -> the (B, V, 16) fp16 pair tensor the split-fp16 kernels exchange
+    (per site hi[8] | lo[8], hi = fp16(h), lo = fp16(h - hi)).  Host-side helper for tests and benches: in the pipeline
+    the producing kernel's epilogue writes this format itself."""
+    B, Cc = h.shape[:2]
+    if Cc != 8:
+        raise NormflowHipError("to_split16: 8 channels expected")
+    hp = h.reshape(B, 8, -1).permute(0, 2, 1).float()
+    hi = hp.half()
+    return torch.cat((hi, (hp - hi.float()).half()), dim=2).contiguous()
+
+
+def from_split16(h16, lattice):
+    """Inverse of to_split16 up to the split's rounding: (B, V, 16) halfs -> (B, 8, *L) fp32 (hi + lo)."""
+    B = h16.shape[0]
+    v = h16[:, :, :8].float() + h16[:, :, 8:].float()
+    return v.permute(0, 2, 1).reshape((B, 8) + tuple(lattice)).contiguous()
+
+
 def conv_layer_split16(h16, weight, bias, act, lattice):
     """Hidden 8 -> 8 layer on fp16 (hi, lo) pairs in and out (nf_conv_fwd_split16); inference only."""
     lib = load()
@@ -491,12 +541,24 @@ def conv_layer_split16(h16, weight, bias, act, lattice):
 _UNIT_OK = {}
 
 
+def invalidate_weight_checks():
+    """Forget every cached verdict of `_weights_fit_fp16` (call after editing weights through `.data`, which does not
+    bump a tensor's version counter)."""
+    _UNIT_OK.clear()
+
+
 def _weights_fit_fp16(w):
     """finite and inside the fp16 range (the split-fp16 kernel's precondition on the weights); cached per
-    parameter version so that the device->host sync happens once per optimiser step, not per launch."""
+    parameter version so that the device->host sync happens once per optimiser step, not per launch.
+    In-place ops under no_grad (optimizers, `p.copy_`) bump the version; writes through `p.data` do NOT -- after
+    those call `invalidate_weight_checks()` (ModelDeviceHandler.broadcast_parameters does).  Under stream capture
+    (GraphedFlow) the check cannot run: only an already cached verdict is accepted, so GraphedFlow validates the
+    weights eagerly before it captures and must be re-captured after the weights change."""
     key = (w.data_ptr(), w._version, tuple(w.shape))
     ok = _UNIT_OK.get(key)
     if ok is None:
+        if torch.cuda.is_current_stream_capturing():
+            return False        # cannot synchronise here; the fp32 kernels are always valid
         if len(_UNIT_OK) > 256:
             _UNIT_OK.clear()
         ok = bool(torch.isfinite(w).all()) and float(w.abs().max()) * SPLIT16_WEIGHT_SCALE < 3.0e4

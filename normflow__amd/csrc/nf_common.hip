@@ -7,6 +7,11 @@ namespace nf {
 
 static thread_local char g_err[512] = "";
 
+// ---- process-wide kernel-selection options (nf_set_option / nf_get_option).  Plain ints written by the host thread that
+// configures the library; kernels never read them, only the launch planners do.
+static int g_options[NF_OPT_COUNT_] = {1, 1};
+int option(int which) { return (which >= 0 && which < NF_OPT_COUNT_) ? g_options[which] : 0; }
+
 void set_error(const char *fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -53,6 +58,16 @@ template int launch_finalize<double>(const double *, int64_t, const void *, void
 }  // namespace nf
 
 extern "C" int nf_version(void) { return NF_VERSION; }
+extern "C" int nf_set_option(int which, int value) {
+  if (which < 0 || which >= NF_OPT_COUNT_) {
+    nf::set_error("nf_set_option: unknown option %d", which);
+    return NF_EINVAL;
+  }
+  const int old = nf::g_options[which];
+  nf::g_options[which] = value;
+  return old;
+}
+extern "C" int nf_get_option(int which) { return nf::option(which); }
 extern "C" const char *nf_last_error_string(void) { return nf::g_err; }
 extern "C" size_t nf_workspace_bytes(int64_t B, int64_t V) {
   if (B < 0 || V < 0) return 0;

@@ -122,7 +122,7 @@ __device__ __forceinline__ void mma_rows(const ConvArgs &A, const T *tile, const
     }
   };
   auto request = [&](T (&a)[K3][KQ][MT], T (&b)[K3][KQ][NT]) {
-    const T *__restrict__ wt = wf + (int64_t((A.dbg & 8) ? 0 : row) * K3 * A.kq_total + kq0) * wstep;   // dbg 8: L1-resident weights (ablation)
+    const T *__restrict__ wt = wf + (int64_t(NF_DBG(A, 8) ? 0 : row) * K3 * A.kq_total + kq0) * wstep;   // dbg 8: L1-resident weights (ablation)
 #pragma unroll
     for (int j3 = 0; j3 < K3; ++j3)
 #pragma unroll
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 && MT == 2) ? 3 : 2) void c
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int nwaves = kBlock / kWave;
   stamp(A, 0);
-  if (A.stamps && threadIdx.x == 0) {     // diagnostic: which CU hosts this workgroup
+  if (NF_STAMPS(A) && threadIdx.x == 0) {     // diagnostic: which CU hosts this workgroup
     const unsigned id = blockIdx.y * gridDim.x + blockIdx.x;
     if (id < 4096u) {
       unsigned hw, xcc;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 && MT == 2) ? 3 : 2) void c
   const int tile_ints = int(sizeof(T) / 4) * A.cchunk * A.S;    // ints occupied by the staged channel planes
   int *rowsrc = reinterpret_cast<int *>(tile) + tile_ints;
   int *rowdst = rowsrc + R;
-  if (!(A.dbg & 1)) {
+  if (!NF_DBG(A, 1)) {
     for (int t = threadIdx.x; t < R; t += kBlock) {
       const int z0 = t / (h1 * h2), rem = t - z0 * (h1 * h2);
       const int z1 = rem / h2, z2 = rem - z1 * h2;
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 && MT == 2) ? 3 : 2) void c
   }
   // copies channels [c0, c0 + cc) of the box + halo into planes [0, cc) of the tile
   auto stage = [&](int c0, int cc) {
-    if (A.dbg & 1) return;
+    if (NF_DBG(A, 1)) return;
     const int creal = A.cin - c0 < cc ? (A.cin - c0 > 0 ? A.cin - c0 : 0) : cc;
     for (int i = threadIdx.x; i < (cc - creal) * A.S; i += kBlock) tile[creal * A.S + i] = T(0);
     for (int z3b = 0; z3b < h3; z3b += kWave) {         // 64-wide chunks of the fastest axis
@@ -379,14 +379,14 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 && MT == 2) ? 3 : 2) void c
     stage(c0, cc);
     __syncthreads();
     stamp(A, c0 ? 4 : 2);
-    if (A.dbg & 2) continue;
+    if (NF_DBG(A, 2)) continue;
     if (A.packed) {
       mma_packed<T, MT, NT>(A, tile, reinterpret_cast<const int *>(tile) + ((tile_ints + 2 * R + 3) & ~3) + g * A.ns,
                             abase, wf, acc);
     } else {
       // whole-row pipelining doubles the fragment registers: only where the accumulator tile leaves room
       // (MT*NT = 12 would exceed 256 VGPR+AGPR and drop to one wave per SIMD)
-      const int rows = ((A.dbg & 4) || MT * NT > 8) ? 0 : A.kt3;
+      const int rows = (NF_DBG(A, 4) || MT * NT > 8) ? 0 : A.kt3;
       switch (cc >> 2) {
         case 1: if (rows == 3) mma_rows<T, MT, NT, 1, 3>(A, tile, abase, wf, acc, c0 >> 2);
                 else if (rows == 4) mma_rows<T, MT, NT, 1, 4>(A, tile, abase, wf, acc, c0 >> 2);
@@ -438,7 +438,7 @@ using namespace nf;
 // 1 if nf_conv_fwd computes this layer with two-site column packing (then the weights must be
 // packed as 16 output columns over k3+1 taps along the fastest axis, see include/normflow_hip.h)
 extern "C" int nf_conv_two_site(int cout, int compact, int l3, int k3) {
-  static const int off = getenv("NF_CONV_NO_TWO_SITE") ? 1 : 0;
+  static const int off = NF_DIAG_ENV_INT("NF_CONV_NO_TWO_SITE", 0);
   return !off && cout <= 8 && !compact && l3 % 2 == 0 && l3 >= 4 && (k3 & 1);
 }
 extern "C" int nf_conv_cin_pad(int cin) { return (cin + 3) & ~3; }
@@ -508,7 +508,7 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
     A.kq = 0; A.kq_total = 0; A.cchunk = cin;
   }
   {
-    static const int dbg = getenv("NF_CONV_DBG") ? atoi(getenv("NF_CONV_DBG")) : 0;
+    static const int dbg = NF_DIAG_ENV_INT("NF_CONV_DBG", 0);
     A.dbg = dbg;
   }
 
@@ -516,13 +516,13 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
   // the fastest axis (coalescing), then as cubic as the lattice allows (least halo).  MT = 4
   // unless the staged box would then exceed ~80 KiB of LDS (two workgroups per CU keep one
   // staging while the other multiplies); then MT = 2.
-  static const int lds_cap_kb = getenv("NF_CONV_LDS_KB") ? atoi(getenv("NF_CONV_LDS_KB")) : 40;
-  static const int box3_cap = getenv("NF_CONV_BOX3") ? atoi(getenv("NF_CONV_BOX3")) : 32;
-  static const int mt_first = getenv("NF_CONV_MT") ? atoi(getenv("NF_CONV_MT")) : 4;
+  static const int lds_cap_kb = NF_DIAG_ENV_INT("NF_CONV_LDS_KB", 40);
+  static const int box3_cap = NF_DIAG_ENV_INT("NF_CONV_BOX3", 32);
+  static const int mt_first = NF_DIAG_ENV_INT("NF_CONV_MT", 4);
   // layers the persistent kernel (nf_conv_pipe.hip) can take are planned with its MT = 2 boxes straight away
-  static const int pipe_off = getenv("NF_CONV_PIPE") ? (atoi(getenv("NF_CONV_PIPE")) == 0) : 0;
+  const int pipe_off = !option(NF_OPT_PIPE);
   const bool pipe_candidate = sizeof(T) == 4 && !pipe_off && !A.packed && A.k[3] == 3 &&
-                              A.k[0] * A.k[1] * A.k[2] >= 2 && A.nt_total <= 3 && !(A.dbg & 15);   // (dbg bits >= 16 are timing ablations inside the persistent kernels)
+                              A.k[0] * A.k[1] * A.k[2] >= 2 && A.nt_total <= 3 && !NF_DBG(A, 15);   // (dbg bits >= 16 are timing ablations inside the persistent kernels)
   int MT = (mt_first == 2 || pipe_candidate) ? 2 : 4;
   int box[4];
   for (int attempt = 0; attempt < 2; ++attempt) {
@@ -555,7 +555,7 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
     }
     int64_t hv = 1;
     for (int mu = 0; mu < 4; ++mu) hv *= box[mu] + A.k[mu] - 1;
-    static const int cplan_max = getenv("NF_CONV_CPLAN") ? atoi(getenv("NF_CONV_CPLAN")) : 8;
+    static const int cplan_max = NF_DIAG_ENV_INT("NF_CONV_CPLAN", 8);
     const int cplan = A.packed ? cin : (A.cin_pad < cplan_max ? A.cin_pad : cplan_max);   // channels planned per K pass
     if (MT == 2 || hv * cplan * int64_t(sizeof(T)) <= int64_t(lds_cap_kb) * 1024) break;
     MT = 2;
@@ -595,7 +595,7 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
     if (lds < stage) lds = stage;
   }
   {
-    static const int pad_kb = getenv("NF_CONV_LDS_PAD_KB") ? atoi(getenv("NF_CONV_LDS_PAD_KB")) : 0;   // occupancy experiments
+    static const int pad_kb = NF_DIAG_ENV_INT("NF_CONV_LDS_PAD_KB", 0);   // occupancy experiments
     lds += size_t(pad_kb) * 1024;
   }
   NF_REQUIRE(lds <= 160 * 1024, "nf_conv_fwd: input box needs %zu B of LDS (> 160 KiB): cin=%d, kernel %dx%dx%dx%d",
@@ -620,7 +620,7 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
   if (fz && (fz->flags & NF_CONV_UNIT_INPUT)) {
     if constexpr (sizeof(T) == 4) {
       if (MT == 2) {     // split-fp16 products, weight-stationary (nf_conv_h.hip)
-        if (fz->flags & NF_CONV_SPLIT16_INPUT) A.dbg |= 0x10000;     // carried to the kernel in a spare bit
+        if (fz->flags & NF_CONV_SPLIT16_INPUT) A.in_split16 = 1;     // carried to the kernel in a spare bit
         const int pr = launch_conv_h(A, B, nblocks, fuse, stream, g_dry_layout != nullptr);
         if (pr == -2) { set_error("nf_conv_rqs: batch x boxes >= 2^31 work items, split the batch"); return NF_EINVAL; }
         if (pr < 0) { set_error("nf_conv_rqs: could not launch the split-fp16 kernel"); return NF_ELAUNCH; }
@@ -658,7 +658,7 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
       if (pr == 1) { g_last_path = 1; return check_launch("conv pipe kernel"); }
     }
   }
-  static const int want_stamps = getenv("NF_CONV_STAMPS") ? atoi(getenv("NF_CONV_STAMPS")) : 0;
+  static const int want_stamps = NF_DIAG_ENV_INT("NF_CONV_STAMPS", 0);
   unsigned long long *d_stamps = nullptr;
   if (want_stamps) {      // DIAGNOSTIC ONLY: allocates and synchronises, never enabled in product use
     (void)hipMalloc(&d_stamps, 4096 * 8 * sizeof(unsigned long long));

@@ -31,6 +31,18 @@ template <> struct Mma<double> {
 enum { kActNone = 0, kActTanh = 1, kActRelu = 2, kActLeakyRelu = 3, kActSoftplus = 4, kActAbs = 5,
        kActSigmoid = 6 };
 
+// Timing ablations (kernels that SKIP work) and clock stamps exist only in diagnostic builds (`make DIAG=1` defines
+// NF_DIAG); in the product library the tests below are compile-time false and the environment is never consulted.
+#ifdef NF_DIAG
+#define NF_DBG(A, bits) ((((A).dbg) & (bits)) != 0)
+#define NF_STAMPS(A) ((A).stamps != nullptr)
+#define NF_DIAG_ENV_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define NF_DBG(A, bits) false
+#define NF_STAMPS(A) false
+#define NF_DIAG_ENV_INT(name, dflt) (dflt)
+#endif
+
 struct ConvArgs {
   const void *in;       // (B, Cin, V) of T
   const void *wfrag;    // [tap][kq][ntile][64] fragment-ordered, zero padded, of T
@@ -51,7 +63,8 @@ struct ConvArgs {
   RqsParams P;
   int packed, ns;       // packed: K = (tap, ci) flattened, 4 per step, ns steps (multiple of 4)
   unsigned long long *stamps;   // diagnostic build only (NF_CONV_STAMPS): 8 clock stamps per workgroup
-  int dbg;              // profiling ablation (NF_CONV_DBG): bit0 skip staging, bit1 skip the MFMA loop
+  int dbg;              // DIAGNOSTIC builds only (make DIAG=1; NF_CONV_DBG / NF_CONVG_DBG timing ablations that skip work): always 0 otherwise
+  int in_split16;       // nf_conv_rqs: `in` is the (B, V, 16) fp16 (hi, lo) pair tensor a previous layer wrote (NF_CONV_SPLIT16_INPUT)
   int64_t nitems;       // nf_conv_pipe.hip: (sample, box) items in the launch, boxes per sample
   int nboxes;
   int out_split16;          // two-site layers with 8 output channels: store (hi, lo) fp16 pairs, channel-last, 32 bytes per site
@@ -125,11 +138,13 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-__device__ __forceinline__ void stamp(const ConvArgs &A, int slot) {
-  if (A.stamps && threadIdx.x == 0) {
+__device__ __forceinline__ void stamp([[maybe_unused]] const ConvArgs &A, [[maybe_unused]] int slot) {
+#ifdef NF_DIAG
+  if (NF_STAMPS(A) && threadIdx.x == 0) {
     const unsigned id = blockIdx.y * gridDim.x + blockIdx.x;
     if (id < 4096u) A.stamps[id * 8 + slot] = __builtin_readcyclecounter();
   }
+#endif
 }
 
 // Epilogue of one box: accumulators -> (bias, activation) -> output planes, or, FUSE > 0, the

@@ -59,8 +59,9 @@ static_assert(LDS_BYTES <= 160 * 1024, "two image pairs and the logit scratch mu
 
 }  // namespace h
 
-#ifndef NF_H_ABL
-#define NF_H_ABL 0      // timing ablations of the compute waves (tools only): 1 no fragment reads, 2 no reduction
+#if !defined(NF_DIAG) || !defined(NF_H_ABL)
+#undef NF_H_ABL
+#define NF_H_ABL 0      // timing ablations of the compute waves (diagnostic builds only, make DIAG=1 with -DNF_H_ABL=..): 1 no fragment reads, 2 no reduction
 #endif
 
 typedef __attribute__((address_space(3))) float lds_f;
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   // channel-last fp16 pairs, 32 bytes per site (NF_CONV_SPLIT16_INPUT: two 16-byte loads, no arithmetic).
   constexpr int PB = 4;                          // passes per batch, two batches in flight
   const int rs = lane >> 5, xs = lane & 31;
-  const bool pre = (A.dbg & 0x10000) != 0;       // input already split (flag carried in the high bits of dbg)
+  const bool pre = A.in_split16 != 0;       // input already split (flag carried in the high bits of dbg)
   auto put = [&](unsigned char *imgH, int row, int x3, const f16x8 &hi, const f16x8 &lo) {
     const int d = (x3 & 1) * SUB + row * ROWB + (x3 >> 1) * 16;
     *reinterpret_cast<f16x8 *>(imgH + d) = hi;
@@ -437,19 +438,19 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   prefetch_x(cb, co4);
   lds_barrier();                                // P: image 0 ready
   for (int m = 0; m < n_my; ++m) {
-    if (m > 0 && !(A.dbg & 128)) epilogue(pb, po, int64_t(vb) + int64_t(m - 1) * nb);     // dbg 128: timing ablation
+    if (m > 0 && !NF_DBG(A, 128)) epilogue(pb, po, int64_t(vb) + int64_t(m - 1) * nb);     // dbg 128: timing ablation
     prefetch_x(cb, co4);                        // for the epilogue of item m, one iteration from now
     int n2b = n1b, n2o[4] = {n1o[0], n1o[1], n1o[2], n1o[3]};
     if (m + 2 < n_my) advance(n2b, n2o);
     // image m+1 goes where image m-1 and then the partial sums of item m-1 were: after the epilogue above
-    if (m + 1 < n_my && !(A.dbg & 64)) {        // dbg 64: timing ablation
-      if (pre) { if (!(A.dbg & 512)) commit_item(smem_h + ((m + 1) & 1) * 2 * IMG); }     // dbg 512: timing ablation, loads only
+    if (m + 1 < n_my && !NF_DBG(A, 64)) {        // dbg 64: timing ablation
+      if (pre) { if (!NF_DBG(A, 512)) commit_item(smem_h + ((m + 1) & 1) * 2 * IMG); }     // dbg 512: timing ablation, loads only
       else stage(n1b, n1o, smem_h + ((m + 1) & 1) * 2 * IMG);
     }
     lds_barrier();                              // B1: image m is consumed, pt is free (committing the next image after this
                                                 //     barrier instead, in the store/add window, was measured: +9 %)
     // the loads of item m+2 go out while the compute waves store and add: this wave has nothing else to do until Bs
-    if (m + 2 < n_my && pre && !(A.dbg & 64)) issue_item(n2b, n2o);
+    if (m + 2 < n_my && pre && !NF_DBG(A, 64)) issue_item(n2b, n2o);
     pb = cb;
     cb = n1b;
     n1b = n2b;
@@ -464,10 +465,9 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
 // 1 = launched (dry: would launch), 0 = not this kernel's layer, < 0 error.  A0 is nf_conv.hip's planned argument block.
 int launch_conv_h(const ConvArgs &A0, int64_t B, int64_t nboxes, int fuse, hipStream_t stream, bool dry) {
   using namespace h;
-  static const int off = getenv("NF_CONV_SPLIT16") ? (atoi(getenv("NF_CONV_SPLIT16")) == 0) : 0;
-  if (off || !fuse) return 0;
+  if (!option(NF_OPT_SPLIT16) || !fuse) return 0;
   ConvArgs A = A0;
-  if (A.cin != 8 || A.cout != C || A.P.m != M || A.P.fx || A.P.fy || (A.dbg & 15) || A.stamps) return 0;   // (bit 0x10000 of dbg: input already split)
+  if (A.cin != 8 || A.cout != C || A.P.m != M || A.P.fx || A.P.fy || NF_DBG(A, 15) || NF_STAMPS(A)) return 0;   // (bit 0x10000 of dbg: input already split)
   for (int mu = 0; mu < 4; ++mu)
     if (A.k[mu] != 3) return 0;
   if (A.box[0] != 2 || A.box[1] != 2 || A.box[2] != 2 || A.box[3] != 32 || A.L[3] != 32) return 0;
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
     // the output of item m-1 leaves while item m multiplies: its transpose (the other ot buffer) is read before a step's
     // MFMAs, converted and stored after them
     const float *otp = ot + ((m + 1) & 1) * (8 * G::CS);
-    const bool outp = m > 0 && !(A.dbg & 4);
+    const bool outp = m > 0 && !NF_DBG(A, 4);
     float ov[8];
     auto out_load = [&](int k) {
       if (outp) {
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
     auto out_store = [&](int k) {
       if (outp) store_site(ov, pcb, pco4, threadIdx.x + 256 * k);
     };
-    if (!(A.dbg & 1)) {
+    if (!NF_DBG(A, 1)) {
       fetch(fA, 0);
 #pragma unroll
       for (int jj = 0; jj < 9; jj += 2) {
@@ -763,12 +763,12 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
     lds_barrier();                  // B0: the image is consumed, this item's ot is complete
     NF_GTICK(2)     // barrier
     // next item's image (loads issued one iteration ago), the loads of the item after next
-    if (m + 1 < n_my && !(A.dbg & 2)) commit_item();
+    if (m + 1 < n_my && !NF_DBG(A, 2)) commit_item();
     NF_GTICK(3)     // commit
     int n2b = n1b, n2o[4] = {n1o[0], n1o[1], n1o[2], n1o[3]};
     if (m + 2 < n_my) {
       advance(n2b, n2o);
-      if (!(A.dbg & 2)) issue_item(n2b, n2o);
+      if (!NF_DBG(A, 2)) issue_item(n2b, n2o);
     }
     NF_GTICK(4)     // issue: 96 KB per item through the CU's 64 B/clk load path -- 1.5 k cycles at best; moved behind the MFMA
                     // steps the same cycles show up there (the waves issue in order)
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
            double(tacc[0]) / n_my, double(tacc[1]) / n_my, double(tacc[2]) / n_my, double(tacc[3]) / n_my, double(tacc[4]) / n_my, double(tacc[5]) / n_my);
 #endif
   // the last item's output
-  if (!(A.dbg & 4)) {
+  if (!NF_DBG(A, 4)) {
     const float *otp = ot + ((n_my - 1) & 1) * (8 * G::CS);
 #pragma unroll
     for (int k = 0; k < NOUT; ++k) {
@@ -804,8 +804,7 @@ using namespace nf;
 
 extern "C" int nf_conv_split16_supported(const int32_t *lattice, const int32_t *ksize, int cin, int cout, int act) {
   using namespace nf::h;
-  static const int off = getenv("NF_CONV_SPLIT16") ? (atoi(getenv("NF_CONV_SPLIT16")) == 0) : 0;
-  if (off || !lattice || !ksize || cin != 8 || cout != 8) return 0;
+  if (!nf::option(NF_OPT_SPLIT16) || !lattice || !ksize || cin != 8 || cout != 8) return 0;
   if (act != kActTanh && act != kActSigmoid) return 0;                    // the OUTPUT must be fp16-safe as well
   for (int mu = 0; mu < 4; ++mu)
     if (ksize[mu] != 3) return 0;
@@ -827,7 +826,7 @@ extern "C" int nf_conv_fwd_split16(const void *in16, const void *wsplit, const v
   ConvArgs A{};
   A.in = in16; A.wfrag = wsplit; A.bias = bias; A.out = out16;
   A.V = 1;
-  static const int bz2_env = getenv("NF_CONVG_BZ2") ? atoi(getenv("NF_CONVG_BZ2")) : 0;        // A/B knob
+  static const int bz2_env = NF_DIAG_ENV_INT("NF_CONVG_BZ2", 0);        // A/B knob
   const int bz2 = bz2_env == 2 ? 2 : ((lattice[2] % 4 == 0) ? 4 : 2);
   const int box[4] = {2, 2, bz2, 32};
   int64_t nboxes = 1;
@@ -839,7 +838,7 @@ extern "C" int nf_conv_fwd_split16(const void *in16, const void *wsplit, const v
   }
   A.cin = 8; A.cout = 8; A.act = act;
   {
-    static const int dbg = getenv("NF_CONVG_DBG") ? atoi(getenv("NF_CONVG_DBG")) : 0;     // timing ablations: 1 no MFMA loop, 2 no staging, 4 no output
+    static const int dbg = NF_DIAG_ENV_INT("NF_CONVG_DBG", 0);     // timing ablations: 1 no MFMA loop, 2 no staging, 4 no output
     A.dbg = dbg;
   }
   A.nitems = B * nboxes;

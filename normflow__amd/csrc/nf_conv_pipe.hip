@@ -386,10 +386,10 @@ __global__ __launch_bounds__(kBlock, 2) void conv_pipe_kernel(ConvArgs A) {
     if (last_chunk && p + 1 < P) decode(vb + (m + 1) * nb, nb_, no_);
     set_next(nb_, no_, last_chunk ? 0 : q + 1, buf + ((p + 1) & 1) * bufsz, last_chunk);
     if constexpr (HOT) phase_mma_hot(cur, q);
-    else phase_mma(cur, q, (p + 1 < P && !(A.dbg & 16)) ? nst_full : 0);     // dbg 16: timing ablation, no staging
+    else phase_mma(cur, q, (p + 1 < P && !NF_DBG(A, 16)) ? nst_full : 0);     // dbg 16: timing ablation, no staging
     lds_barrier();      // everyone is done reading `cur`; the next phase's planes are complete
     if (last_chunk) {
-      if (!(A.dbg & 32))                                    // dbg 32: timing ablation, no epilogue
+      if (!NF_DBG(A, 32))                                    // dbg 32: timing ablation, no epilogue
       conv_epilogue<T, MT, NT, COMPACT, FUSE>(A, co, cb, int64_t(vb) + int64_t(m) * nb, acc, cur, red, wave, lane);
       lds_barrier();                                    // `cur` may have served as scratch; it is staged into next
       cb = nb_;
@@ -427,8 +427,8 @@ static int launch_pipe_w(const ConvArgs &A, size_t lds, hipStream_t stream) {
 
 template <int MT, int NT, int K3, bool COMPACT, int FUSE>
 static int launch_pipe_one(const ConvArgs &A, size_t lds, hipStream_t stream) {
-  static const int hot_off = getenv("NF_CONV_PIPE_ROLLED") ? 1 : 0;      // A/B knob
-  const bool hot = !hot_off && A.wide_no == 2 && A.k[0] == 3 && A.k[1] == 3 && A.k[2] == 3 && !(A.dbg & 16);
+  static const int hot_off = NF_DIAG_ENV_INT("NF_CONV_PIPE_ROLLED", 0);      // A/B knob
+  const bool hot = !hot_off && A.wide_no == 2 && A.k[0] == 3 && A.k[1] == 3 && A.k[2] == 3 && !NF_DBG(A, 16);
   if (hot) return launch_pipe_w<MT, NT, K3, COMPACT, FUSE, true, true>(A, lds, stream);
   return A.wide_no ? launch_pipe_w<MT, NT, K3, COMPACT, FUSE, true, false>(A, lds, stream)
                    : launch_pipe_w<MT, NT, K3, COMPACT, FUSE, false, false>(A, lds, stream);
@@ -438,13 +438,13 @@ static int launch_pipe_one(const ConvArgs &A, size_t lds, hipStream_t stream) {
 // the one-box kernel), < 0 on error.  `A0` is the fully planned argument block of nf_conv.hip
 // (MT = 2 boxes); only the plane stride is re-planned (slack for masked stores).
 int launch_conv_pipe(const ConvArgs &A0, int64_t B, int64_t nboxes, int fuse, hipStream_t stream, bool dry) {
-  static const int off = getenv("NF_CONV_PIPE") ? (atoi(getenv("NF_CONV_PIPE")) == 0) : 0;
+  const int off = !option(NF_OPT_PIPE);
   if (off) return 0;
   ConvArgs A = A0;
-  if (A.packed || A.k[3] != 3 || (A.dbg & 15) || A.stamps) return 0;    // cin % 4 != 0 (>= 8): channel planes zero-padded in LDS
+  if (A.packed || A.k[3] != 3 || NF_DBG(A, 15) || NF_STAMPS(A)) return 0;    // cin % 4 != 0 (>= 8): channel planes zero-padded in LDS
   A.wide_no = 0; A.wide_llpr = 0;
   {
-    static const int wide_off = getenv("NF_CONV_PIPE_NARROW") ? 1 : 0;     // A/B knob
+    static const int wide_off = NF_DIAG_ENV_INT("NF_CONV_PIPE_NARROW", 0);     // A/B knob
     const int L3 = A.L[3];
     int64_t rows3 = 1;
     for (int mu = 0; mu < 3; ++mu) rows3 *= A.hal[mu];
@@ -694,11 +694,11 @@ __global__ __launch_bounds__(kBlock, 2) void conv_c1_kernel(ConvArgs A) {
     const T *cur = buf + (m % 3) * A.S;
     if (m + 2 < n_my) advance(b2, o2);
     set_next(b2, o2);
-    if (!(A.dbg & 256)) issue_all(sh_issue);                 // item m + 2 -> registers (dbg 256: timing ablation)
+    if (!NF_DBG(A, 256)) issue_all(sh_issue);                 // item m + 2 -> registers (dbg 256: timing ablation)
     acc_t acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = acc_t{0.f, 0.f, 0.f, 0.f};
-    if (!(A.dbg & 128)) {                                    // dbg 128: timing ablation
+    if (!NF_DBG(A, 128)) {                                    // dbg 128: timing ablation
       // A values are read three kernel rows ahead into named buffers; left to itself the compiler serialises
       // ds_read -> wait -> MFMA through one register and exposes the LDS latency 27*MT times per item
       constexpr int NG3 = NROWS / 3;
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_c1_kernel(ConvArgs A) {
         const int z1 = zr & (A.box[1] - 1);
         zr >>= A.lbox[1];
         const int x0 = co4[0] + zr, x1 = co4[1] + z1, x2 = co4[2] + z2, x3 = co4[3] + 4 * c4;
-        if (c < A.cout && x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2] && x3 < A.L[3] && !(A.dbg & 64))   // dbg 64: timing ablation
+        if (c < A.cout && x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2] && x3 < A.L[3] && !NF_DBG(A, 64))   // dbg 64: timing ablation
           *reinterpret_cast<acc_t *>(out_b + int64_t(c) * A.V + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + x3) = v;
       }
     }
@@ -851,10 +851,10 @@ static int launch_c1(const ConvArgs &A, size_t lds, hipStream_t stream) {
 
 // 1 = launched, 0 = not this kernel's layer, < 0 = error.  `MT` is the box size nf_conv.hip planned (2 or 4).
 int launch_conv_c1(const ConvArgs &A0, int MT, int64_t B, int64_t nboxes, hipStream_t stream) {
-  static const int off = getenv("NF_CONV_PIPE") ? (atoi(getenv("NF_CONV_PIPE")) == 0) : 0;
+  const int off = !option(NF_OPT_PIPE);
   if (off) return 0;
   ConvArgs A = A0;
-  if (A.cin != 1 || !A.sh2 || A.k[3] != 3 || (A.dbg & 15) || A.stamps || A.compact) return 0;
+  if (A.cin != 1 || !A.sh2 || A.k[3] != 3 || NF_DBG(A, 15) || NF_STAMPS(A) || A.compact) return 0;
   if (A.out_split16 && A.cout != 8) return 0;
   const int nrows = A.k[0] * A.k[1] * A.k[2];
   if (nrows != 27 && nrows != 9 && nrows != 3) return 0;

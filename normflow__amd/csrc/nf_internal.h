@@ -13,6 +13,7 @@ constexpr int kMaxBlocksX = 65535 * 16;
 
 void set_error(const char *fmt, ...);
 int check_launch(const char *what);
+int option(int which);      // nf_set_option / nf_get_option (nf_common.hip)
 
 #define NF_REQUIRE(cond, ...)                \
   do {                                       \

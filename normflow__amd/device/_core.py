@@ -17,6 +17,7 @@ from functools import partial
 
 import torch
 import torch.distributed as dist
+from torch.multiprocessing.spawn import ProcessException
 from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
 
 
@@ -45,20 +46,22 @@ class ModelDeviceHandler:
         self.nranks, self.rank = nranks, rank
         self.broadcast_parameters()
 
-    def _tensors(self):
-        net_ = self._model.net_
-        return [p.data for p in net_.parameters()]
-
     def broadcast_parameters(self, src=0):
+        """Every rank takes rank `src`'s parameters.  The copy goes through the parameter itself (under no_grad), not
+        through `.data`: it bumps the tensors' version counters, which the split-fp16 range check of the conv kernels
+        keys on (`_hip._weights_fit_fp16`); that cache is dropped as well."""
         if self.nranks == 1:
             return
-        tensors = self._tensors()
-        for dtype in {t.dtype for t in tensors}:
-            group = [t for t in tensors if t.dtype == dtype]
-            flat = _flatten_dense_tensors(group)
-            dist.broadcast(flat, src=src)
-            for t, new in zip(group, _unflatten_dense_tensors(flat, group)):
-                t.copy_(new)
+        params = list(self._model.net_.parameters())
+        with torch.no_grad():
+            for dtype in {p.dtype for p in params}:
+                group = [p for p in params if p.dtype == dtype]
+                flat = _flatten_dense_tensors([p.detach() for p in group])
+                dist.broadcast(flat, src=src)
+                for p, new in zip(group, _unflatten_dense_tensors(flat, group)):
+                    p.copy_(new)
+        from .. import _hip
+        _hip.invalidate_weight_checks()
 
     def all_reduce_gradients(self):
         """Mean of the gradients over ranks: one flat buffer, one collective."""
@@ -90,7 +93,7 @@ class ModelDeviceHandler:
             torch.multiprocessing.spawn(partial(worker, **kwargs),
                                         args=(nranks, master_port, seeds_torch, self._model) + tuple(args),
                                         nprocs=nranks, join=True)
-        except torch.multiprocessing.spawn.ProcessException:
+        except ProcessException:
             warnings.warn("Distributed run could not be spawned; if the master port is in use, "
                           "pass another one via master_port.")
             raise

@@ -20,21 +20,34 @@ class GraphedFlow:
             raise ValueError("GraphedFlow needs a CUDA/HIP tensor")
         self._x = example_x.detach().clone()
         self._log0 = None if log0 is None else log0.detach().clone()
-        fn = net_.backward if inverse else net_.forward
+        self._net, self._inverse, self._warmup = net_, inverse, warmup
+        self._capture()
+
+    def _param_state(self):
+        return tuple((p.data_ptr(), p._version) for p in self._net.parameters())
+
+    def _capture(self):
+        fn = self._net.backward if self._inverse else self._net.forward
         call = (lambda: fn(self._x)) if self._log0 is None else (lambda: fn(self._x, self._log0))
-        side = torch.cuda.Stream(device=example_x.device)
-        side.wait_stream(torch.cuda.current_stream(example_x.device))
+        dev = self._x.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
         with torch.no_grad(), torch.cuda.stream(side):
-            for _ in range(warmup):                   # one-time initialisation (function attributes, workspaces) outside the capture
-                call()
-        torch.cuda.current_stream(example_x.device).wait_stream(side)
+            for _ in range(self._warmup):             # one-time initialisation (function attributes, the host-side range
+                call()                                # checks of the split-fp16 kernels) outside the capture
+        torch.cuda.current_stream(dev).wait_stream(side)
         self._graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self._graph):
             self._y, self._logj = call()
+        self._state = self._param_state()
 
     def __call__(self, x, log0=None, clone=True):
         if x.shape != self._x.shape or x.dtype != self._x.dtype:
             raise ValueError(f"GraphedFlow was captured for {tuple(self._x.shape)} {self._x.dtype}, got {tuple(x.shape)} {x.dtype}")
+        if self._param_state() != self._state:
+            # the parameters changed since the capture (optimizer step, load_state_dict): the kernel choice frozen into
+            # the graph (split-fp16 products need weights inside the fp16 range) was validated for the OLD values
+            self._capture()
         self._x.copy_(x)
         if self._log0 is not None:
             if log0 is None:

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert set(_hip.PROTOTYPES) == declared
-    assert _hip.load().nf_version() == 100
+    assert _hip.load().nf_version() == 200
 
 
 def test_argument_validation_without_gpu():
@@ -47,6 +47,48 @@ def test_argument_validation_without_gpu():
     assert lib.nf_workspace_bytes(4, 1024) > 0
     with pytest.raises(NotImplementedError):
         _hip.make_rqs_opts(4, (0, 1), (0, 1), {'left': 'periodic'}, 0)
+
+
+def test_kernel_selection_options_in_process():
+    """nf_set_option / nf_get_option: the in-process switch between the split-fp16 and the exact-fp32-product kernels (what
+    bench.py's second value and the headline parity tests use; the library reads no environment variable)."""
+    lib = _hip.load()
+    assert lib.nf_get_option(_hip.OPT_SPLIT16) == 1 and lib.nf_get_option(_hip.OPT_PIPE) == 1
+    lat = (ctypes.c_int32 * 4)(4, 4, 4, 32)
+    k3 = (ctypes.c_int32 * 4)(3, 3, 3, 3)
+    assert lib.nf_conv_split16_supported(lat, k3, 8, 8, 1) == 1
+    assert lib.nf_conv_weight_layout(lat, k3, 8, 46, 1, 3, _hip.NF_F32) == 2         # NF_WLAYOUT_SPLIT16
+    with _hip.options(split16=False):
+        assert lib.nf_get_option(_hip.OPT_SPLIT16) == 0
+        assert lib.nf_conv_split16_supported(lat, k3, 8, 8, 1) == 0
+        assert lib.nf_conv_weight_layout(lat, k3, 8, 46, 1, 3, _hip.NF_F32) == 1     # row-packed fp32 kernel
+        with _hip.options(pipe=False):
+            assert lib.nf_conv_weight_layout(lat, k3, 8, 46, 1, 3, _hip.NF_F32) == 0
+    assert lib.nf_get_option(_hip.OPT_SPLIT16) == 1 and lib.nf_get_option(_hip.OPT_PIPE) == 1
+    assert lib.nf_set_option(99, 1) == -1 and b"unknown option" in lib.nf_last_error_string()
+
+
+def test_product_library_reads_no_environment():
+    """Timing ablations that skip work (NF_CONV_DBG, NF_CONVG_DBG, NF_H_ABL), clock stamps and planner knobs exist only in
+    `make DIAG=1` builds: the shipped library has no getenv import at all."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--undefined-only", _hip.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in out
+
+
+def test_bench_multi_gpu_launch_contract():
+    """bench.py --gpus N: (1) without a launcher it starts the ranks itself -- and refuses, before touching any GPU, when
+    the box has fewer devices; (2) under a launcher whose WORLD_SIZE differs from --gpus it exits non-zero instead of
+    printing a number for the wrong world."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NF_BENCH_REHEARSAL")}
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True)
+        assert r.returncode == 2 and "only" in r.stderr and r.stdout.strip() == ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"],
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True)
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr and r.stdout.strip() == ""
 
 
 def test_product_path_refuses_cpu_tensors():

@@ -101,3 +101,18 @@ def test_single_rank_helpers_are_noops():
     assert (dh.rank, dh.nranks) == (0, 1)
     seeds = nf.device._core.prepare_seeds(3, None)
     assert len(seeds) == 3 and all(isinstance(s, int) for s in seeds)
+
+
+def _failing_worker(model):
+    raise RuntimeError("worker failed on purpose")
+
+
+def test_spawnprocesses_reports_a_failed_child():
+    """A child that raises must surface as the port-hint warning plus the child's own exception (the reference catches
+    torch.multiprocessing.spawn.ProcessException, src/device/_core.py:80-84), not as an AttributeError in the handler."""
+    import pytest
+    from torch.multiprocessing.spawn import ProcessRaisedException
+    model = make_cpu_model(seed=1)
+    with pytest.warns(UserWarning, match="master_port"):
+        with pytest.raises(ProcessRaisedException, match="worker failed on purpose"):
+            model.device_handler.spawnprocesses(_failing_worker, 2, _free_port(), [1, 2])

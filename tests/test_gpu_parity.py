@@ -6,10 +6,13 @@ plus size-independent properties at BASELINE.json's full sizes.
 
 Tolerances (north_star: "within 1e-5 relative fp32 tolerance"):
   fp64 kernels : 1e-9  relative (only formula re-association separates them from the fp64 reference)
-  fp32 kernels : 1e-5  relative on the transformed field and on log|J|, at the KERNEL boundary
-                 (same logits in); gradients 2e-4.  At the MODULE boundary (fp32 conv in
-                 front) the bound is 2e-4: the reference's own fp32-vs-fp64 floor there is
-                 6e-5, set by the conv's rounding, not the kernels.
+  fp32 kernels : 1e-5  relative on the transformed field and on log|J| (north_star's bound); gradients 2e-4.
+                 Where a golden case is ill-conditioned in single precision the bound is
+                 max(1e-5, 2 * err_ref_fp32), err_ref_fp32 = the error of THE REFERENCE'S OWN float32 run of that
+                 case against its float64 run, read from tests/golden/ref_fp32.npz (make_golden_fp32.py ran the
+                 reference in float32 on the goldens' inputs) -- a measured floor per case and per quantity, never a
+                 blanket constant.  Cases without a reference fixture (inputs seeded on the GPU) use the CPU oracle
+                 run in float32 the same way (`oracle_fp32_floor`).
 relative = max|a-b| / max(1, max|b|).
 """
 import os
@@ -41,6 +44,27 @@ def rel(a, b):
     return float((a - b).abs().max()) / max(1.0, float(b.abs().max()))
 
 
+_REF32 = None
+
+
+def ref32(fam, key):
+    """float32 output of the reference itself for golden `fam`/`key` (tests/golden/ref_fp32.npz)."""
+    global _REF32
+    if _REF32 is None:
+        _REF32 = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_fp32.npz"), allow_pickle=False)
+    return torch.from_numpy(_REF32[f"{fam}/{key}"]).double()
+
+
+def floor_tol(z, fam, key, base, sel=None, target=None):
+    """max(base, 2 * err_ref_fp32): err_ref_fp32 = relative error of the reference's float32 run against `target`
+    (default: its own float64 golden `key`), optionally on a subset `sel` of the last axis."""
+    a = ref32(fam, key)
+    b = torch.from_numpy(np.asarray(z[key] if target is None else target)).double().reshape(a.shape)
+    if sel is not None:
+        a, b = a.reshape(-1, sel.numel())[:, sel.cpu()], b.reshape(-1, sel.numel())[:, sel.cpu()]
+    return max(base, 2.0 * rel(a, b))
+
+
 def compact(t, act):
     """(B, C, V) full-lattice tensor -> (B, C, V/2): the active site's column of every pair."""
     B, C, V = t.shape
@@ -54,6 +78,29 @@ def uncompact(t, act):
     pick = act.reshape(-1, 2)[:, 0].bool()
     z = torch.zeros_like(t)
     return torch.stack((torch.where(pick, t, z), torch.where(pick, z, t)), dim=-1).reshape(B, C, 2 * Vh)
+
+
+def check_fused_round_trip(cpl, net, acts, xa, xf, yf, lf, l0, parity, shape, lim, nb=4):
+    """inverse(forward) through the fused kernels.  (a) whole batch, the well-conditioned statement: pushing the recovered
+    x forward again lands on y (2e-5: two fp32 passes).  (b) x itself and the cancelling log-Jacobians on `nb` samples,
+    bounded by max(1e-5, 2 * floor), floor = the same round trip by the CPU oracle run in FLOAT32 (the reference's
+    arithmetic restated; x = f^-1(y) is conditioned by 1/g, which random-init nets push to ~1e-3)."""
+    B = xa.shape[0]
+    xb, lb = cpl._fused_atom(True, yf, xf, parity, net, lf)
+    y2, _ = cpl._fused_atom(False, xb, xf, parity, net, l0)
+    assert rel(y2, yf) <= 2e-5, ("forward residual of the inverse", rel(y2, yf))
+    nb = min(nb, B)
+    convs = [mod for mod in net if hasattr(mod, 'weight')]
+    layers = [(c.weight.detach().float().cpu(), c.bias.detach().float().cpu()) for c in convs]
+    am = O.channel_mask(shape, parity, dtype=torch.float32)
+    out32 = O.conv_act(xf[:nb].float().cpu().unsqueeze(1), layers, acts)
+    y32, l32 = O.rqs_coupling_atom(xa[:nb].float().cpu(), out32, am, log0=l0[:nb].float().cpu(), **lim)
+    x32, b32 = O.rqs_coupling_atom(y32, out32, am, inverse=True, log0=l32, **lim)
+    tx = max(1e-5, 2.0 * rel(x32, xa[:nb]))
+    tl = max(1e-5, 2.0 * rel(b32, l0[:nb]))
+    assert rel(xb[:nb], xa[:nb]) <= tx, ("round trip x", rel(xb[:nb], xa[:nb]), tx)
+    assert rel(lb[:nb], l0[:nb]) <= tl, ("round trip logJ", rel(lb[:nb], l0[:nb]), tl)
+    return xb, lb
 
 
 def layouts_for(shape):
@@ -109,10 +156,12 @@ def test_atoms_against_reference_goldens(golden, tag, dtype):
             keep[::3] = False
         keep_p = compact(keep.reshape(1, 1, V).to(torch.uint8) * act.reshape(1, 1, V), act).reshape(-1).bool() \
             if layout == "pair" else keep
-        lj_tol = tol["val"] if (dtype == torch.float64 or kind != "rqs_lin") else 2e-4
+        f32 = dtype == torch.float32
+        ft = lambda key, base, **kw: floor_tol(z, "atoms", f"{tag}/{key}", base, **kw) if f32 else base
+        lj_tol = ft("logJ", tol["val"])
         y, logJ = apply(v, False, g("log0"))
-        assert rel(y.reshape(x.shape), g("y")) <= tol["val"], (tag, layout, "y")
-        assert rel(logJ, g("logJ")) <= lj_tol, (tag, layout, "logJ")
+        assert rel(y.reshape(x.shape), g("y")) <= tol["val"], (tag, layout, "y", rel(y.reshape(x.shape), g("y")))
+        assert rel(logJ, g("logJ")) <= lj_tol, (tag, layout, "logJ", rel(logJ, g("logJ")), lj_tol)
         loss = logJ.mean() + (y ** 2).mean()
         gv, gp = torch.autograd.grad(loss, (v, params))
         gxr = g("grad_x").reshape(v.shape)
@@ -123,15 +172,23 @@ def test_atoms_against_reference_goldens(golden, tag, dtype):
         # inverse + its VJP (checked against autograd through the CPU oracle)
         yin = g("y").reshape(v.shape).clone().requires_grad_(True)
         xh, lrt = apply(yin, True, g("logJ"))
-        if dtype == torch.float64 or kind != "rqs_lin":
+        if not f32:
             assert rel(xh.reshape(x.shape), g("x_active")) <= 200 * tol["val"], (tag, layout, "xhat")
             assert rel(lrt, g("log0")) <= 200 * tol["val"], (tag, layout, "logJ_rt")
         else:
-            # wide-logit goldens reach g ~ 1e-4: x = f^-1(y) is ill-conditioned in fp32 (plain
-            # torch fp32 -- the reference's own fp32 arithmetic -- is off by up to 0.12 here,
-            # these kernels by 0.04); the well-conditioned statement is the forward residual
+            # x = f^-1(y) is conditioned by 1/g (these goldens reach g ~ 1e-4): the bound is the reference's own float32
+            # inverse on the same inputs, measured where its float64 inverse round-trips at all (its root formula fails
+            # in the linear tails) -- and always the well-conditioned statement, the forward residual
+            ok = (T(z[f"{tag}/xhat"]) - T(z[f"{tag}/x_active"])).abs().reshape(B, -1).max(dim=0).values < 1e-9
+            if multi:
+                ok = (T(z[f"{tag}/xhat"]) - T(z[f"{tag}/x_active"])).abs().reshape(B * 2, -1).max(dim=0).values < 1e-9
+            xt = ft("xhat", tol["val"], sel=ok, target=z[f"{tag}/x_active"])
+            xe = rel(xh.reshape(B, -1, ok.numel())[..., ok], g("x_active").reshape(B, -1, ok.numel())[..., ok])
+            assert xe <= xt, (tag, layout, "xhat", xe, xt)
+            lt = ft("logJ_rt", tol["val"], target=z[f"{tag}/log0"])
+            assert rel(lrt, g("log0")) <= lt, (tag, layout, "logJ_rt", rel(lrt, g("log0")), lt)
             y2, _ = apply(xh.detach(), False, None)
-            assert rel(y2.reshape(x.shape), g("y")) <= 1e-4, (tag, layout, "inverse residual")
+            assert rel(y2.reshape(x.shape), g("y")) <= 10 * tol["val"], (tag, layout, "inverse residual", rel(y2.reshape(x.shape), g("y")))
         if dtype == torch.float64 and kind not in ("multirqs",):
             linv = lrt.mean() + (xh ** 2).mean()
             gy, gp2 = torch.autograd.grad(linv, (yin, params))
@@ -169,19 +226,22 @@ def test_distconvertor_against_reference_goldens(golden, tag, dtype):
     y, logJ = dc(x, T(z[f"{tag}/log0"], dtype))
     # fp32: expit/logit lose relative accuracy in the tails |x| >~ 7 (1 - u is not representable);
     # the goldens draw x ~ N(0, 2^2), so a handful of points sit there
-    vt = tol["val"] if dtype == torch.float64 else 2e-4
-    assert rel(y, z[f"{tag}/y"]) <= vt
-    assert rel(logJ, z[f"{tag}/logJ"]) <= vt
+    f32 = dtype == torch.float32
+    ft = lambda key, base, **kw: floor_tol(z, "distconv", f"{tag}/{key}", base, **kw) if f32 else base
+    assert rel(y, z[f"{tag}/y"]) <= ft("y", tol["val"]), ("y", rel(y, z[f"{tag}/y"]), ft("y", tol["val"]))
+    assert rel(logJ, z[f"{tag}/logJ"]) <= ft("logJ", tol["val"]), ("logJ", rel(logJ, z[f"{tag}/logJ"]), ft("logJ", tol["val"]))
     loss = logJ.mean() + (y ** 2).mean()
     ps = [sp.weights_x, sp.weights_y] + ([] if smooth else [sp.weights_d])
     grads = torch.autograd.grad(loss, [x] + ps)
-    gt = tol["grad"] if dtype == torch.float64 else 2e-3
     for gr, name in zip(grads, ["grad_x", "grad_wx", "grad_wy", "grad_wd"]):
-        assert rel(gr, z[f"{tag}/{name}"]) <= gt, name
+        gt = ft(name, tol["grad"])
+        assert rel(gr, z[f"{tag}/{name}"]) <= gt, (name, rel(gr, z[f"{tag}/{name}"]), gt)
     with torch.no_grad():
         xh, lrt = dc.backward(T(z[f"{tag}/y"], dtype), T(z[f"{tag}/logJ"], dtype))
-    assert rel(xh, z[f"{tag}/x"]) <= 100 * vt
-    assert rel(lrt, z[f"{tag}/log0"]) <= 100 * vt
+    xt = ft("xhat", tol["val"], target=z[f"{tag}/x"]) if f32 else 100 * tol["val"]
+    lt = ft("logJ_rt", tol["val"], target=z[f"{tag}/log0"]) if f32 else 100 * tol["val"]
+    assert rel(xh, z[f"{tag}/x"]) <= xt, ("xhat", rel(xh, z[f"{tag}/x"]), xt)
+    assert rel(lrt, z[f"{tag}/log0"]) <= lt, ("logJ_rt", rel(lrt, z[f"{tag}/log0"]), lt)
     if dtype == torch.float64:   # VJP of the inverse chain against autograd through the oracle
         yin = T(z[f"{tag}/y"], dtype).requires_grad_(True)
         xh, lrt = dc.backward(yin, T(z[f"{tag}/logJ"], dtype))
@@ -221,17 +281,20 @@ def test_coupling_blocks_with_convact_against_goldens(golden, kind, d, dtype):
     tag = f"{kind}/d{d}"
     shape = tuple(int(v) for v in z[f"{tag}/shape"])
     cpl = _load_block(z, tag, kind, d, shape, dtype)
-    vt, gt = (1e-9, 1e-7) if dtype == torch.float64 else (2e-4, 2e-3)
+    f32 = dtype == torch.float32
+    # fp32 at the module boundary (an fp32 conv stack in front of the coupling): the reference's own float32 run of the
+    # same block sets the floor, per quantity (ref_fp32.npz); never looser than 2x that, never tighter than 1e-5 / 2e-4
+    ft = lambda key, base: floor_tol(z, "blocks", f"{tag}/{key}", base) if f32 else {1e-5: 1e-9, 2e-4: 1e-7}[base]
     x = T(z[f"{tag}/x"], dtype).requires_grad_(True)
     y, logJ = cpl(x)
-    assert rel(y, z[f"{tag}/y"]) <= vt
-    assert rel(logJ, z[f"{tag}/logJ"]) <= vt
+    assert rel(y, z[f"{tag}/y"]) <= ft("y", 1e-5), ("y", rel(y, z[f"{tag}/y"]), ft("y", 1e-5))
+    assert rel(logJ, z[f"{tag}/logJ"]) <= ft("logJ", 1e-5), ("logJ", rel(logJ, z[f"{tag}/logJ"]), ft("logJ", 1e-5))
     loss = logJ.mean() + (y ** 2).mean()
     names = [n for n, _ in cpl.named_parameters()]
     grads = torch.autograd.grad(loss, [x] + [p for _, p in cpl.named_parameters()])
-    assert rel(grads[0], z[f"{tag}/grad_x"]) <= gt
+    assert rel(grads[0], z[f"{tag}/grad_x"]) <= ft("grad_x", 2e-4), ("grad_x", rel(grads[0], z[f"{tag}/grad_x"]))
     for n, gp in zip(names, grads[1:]):
-        assert rel(gp, z[f"{tag}/gparam/{n}"]) <= gt, n
+        assert rel(gp, z[f"{tag}/gparam/{n}"]) <= ft(f"gparam/{n}", 2e-4), (n, rel(gp, z[f"{tag}/gparam/{n}"]))
     with torch.no_grad():
         xh, lrt = cpl.backward(T(z[f"{tag}/y"], dtype), T(z[f"{tag}/logJ"], dtype))
         if dtype == torch.float64:
@@ -241,7 +304,7 @@ def test_coupling_blocks_with_convact_against_goldens(golden, kind, d, dtype):
             # (error ~ 1e-7 / g per layer); the well-conditioned statement is the residual:
             # pushing the recovered x forward again must land on y
             y2, lj2 = cpl(xh)
-            assert rel(y2, z[f"{tag}/y"]) <= 2e-3
+            assert rel(y2, z[f"{tag}/y"]) <= 1e-4, rel(y2, z[f"{tag}/y"])
 
 
 def test_c1_readme_model_against_golden(golden):
@@ -616,8 +679,7 @@ def test_fused_conv_spline_epilogue_matches_unfused(m, shape):
             act = mask.activity(parity).reshape(-1).to(DEV)
             yu, lu = _hip.RQSCouplingFn.apply(xa.reshape(5, -1), params, l0, act, opts, False)
             assert rel(yf.reshape(5, -1), yu) <= 2e-6 and rel(lf, lu) <= 2e-6
-            xb, lb = cpl._fused_atom(True, yf, xf, parity, net, lf)
-            assert rel(xb, xa) <= 5e-4 and rel(lb, l0) <= 5e-4
+            check_fused_round_trip(cpl, net, ['tanh', 'tanh', None], xa, xf, yf, lf, l0, parity, shape, lim, nb=5)
         convs = [mod for mod in net if hasattr(mod, 'weight')]
         layers = [(c.weight.detach().double().cpu(), c.bias.detach().double().cpu()) for c in convs]
         out = O.conv_act(xf.double().cpu().unsqueeze(1), layers, ['tanh', 'tanh', None])
@@ -715,8 +777,7 @@ def test_fused_epilogue_on_pipelined_kernel_multi_item():
             act = mask.activity(parity).reshape(-1).to(DEV)
             yu, lu = _hip.RQSCouplingFn.apply(xa.reshape(B, -1), params, l0, act, opts, False)
             assert rel(yf.reshape(B, -1), yu) <= 2e-6 and rel(lf, lu) <= 2e-6
-            xb, lb = cpl._fused_atom(True, yf, xf, parity, net, lf)
-            assert rel(xb, xa) <= 5e-4 and rel(lb, l0) <= 5e-4
+            check_fused_round_trip(cpl, net, ['tanh', 'tanh', None], xa, xf, yf, lf, l0, parity, shape, lim)
         if parity == 0:
             convs = [mod for mod in net if hasattr(mod, 'weight')]
             layers = [(c.weight.detach().double().cpu(), c.bias.detach().double().cpu()) for c in convs]
@@ -979,9 +1040,8 @@ def test_split_fp16_fused_last_layer(shape, B):
             act = mask.activity(parity).reshape(-1).to(DEV)
             yu, lu = _hip.RQSCouplingFn.apply(xa.reshape(B, -1), params, l0, act, opts, False)
             assert rel(yf.reshape(B, -1), yu) <= 5e-6 and rel(lf, lu) <= 5e-6
-            xb, lb = cpl._fused_atom(True, yf, xf, parity, net, lf)
+            check_fused_round_trip(cpl, net, ['tanh', 'tanh', None], xa, xf, yf, lf, l0, parity, shape, lim)
             assert _hip.load().nf_conv_last_path() == 3
-            assert rel(xb, xa) <= 5e-4 and rel(lb, l0) <= 5e-4
             perm = torch.randperm(B, device=DEV)
             yp, lp = cpl._fused_atom(False, xa[perm], xf[perm], parity, net, l0[perm])
             assert torch.equal(yp, yf[perm]) and torch.equal(lp, lf[perm])          # deterministic, sample-independent
@@ -1068,3 +1128,96 @@ def test_split_fp16_guards_and_graph_replay():
         last.weight[0, 0, 0, 0, 0, 0] = w_old
         y5, l5 = cpl(x)
     assert _hip.load().nf_conv_last_path() == 3 and torch.equal(y5, y) and torch.equal(l5, lj)
+
+
+# -------------------------------------------------- the headline network itself (bench.build_net), end to end
+def _oracle_nets(cpl, dtype):
+    nets = []
+    for net in cpl.nets:
+        convs = [mod for mod in net if hasattr(mod, 'weight')]
+        layers = [(c.weight.detach().to('cpu', dtype), c.bias.detach().to('cpu', dtype)) for c in convs]
+        nets.append(lambda t, layers=layers: O.conv_act(t, layers, ['tanh', 'tanh', None]))
+    return nets
+
+
+def test_headline_network_vs_fp64_oracle():
+    """bench.py's own network (bench.build_net: 8 RQ-spline layers m=16, ConvAct 1-8-8-46, logits rescaled to std 0.5) on a
+    32-wide 4-D lattice the CPU oracle can afford, through the SAME kernels as the timed run (first layer -> fp16 pairs,
+    split-fp16 hidden layer, split-fp16 fused last layer), against the fp64 oracle after all 8 layers: north_star's 1e-5
+    on y and log|J|, or twice the error of the oracle run in float32 on the same network where 8 stacked fp32 layers are
+    further than that from fp64 (the reference's own fp32 whole-net floor is 6e-5 on y)."""
+    import bench
+    lattice, B = (16, 16, 16, 32), 2
+    net_, cpl = bench.build_net(lattice, 8, 16, DEV, seed=2024)
+    g = torch.Generator(device=DEV).manual_seed(1234)
+    x = torch.randn((B,) + lattice, device=DEV, dtype=torch.float32, generator=g)
+    with torch.no_grad():
+        y, lj = net_(x)
+        assert _hip.load().nf_conv_last_path() == 3, "the split-fp16 kernels did not run"
+        with _hip.options(split16=False):
+            y32, lj32 = net_(x)
+            assert _hip.load().nf_conv_last_path() != 3
+    lim = dict(xlim=(-5.0, 5.0), ylim=(-5.0, 5.0), extrap={'left': 'linear', 'right': 'linear'})
+    yo, lo = O.coupling_block(x.double().cpu(), _oracle_nets(cpl, torch.float64), 'rqs', lattice, **lim)
+    yf, lf = O.coupling_block(x.float().cpu(), _oracle_nets(cpl, torch.float32), 'rqs', lattice, **lim)
+    floor_y, floor_l = rel(yf, yo), rel(lf, lo)
+    ty, tl = max(1e-5, 2 * floor_y), max(1e-5, 2 * floor_l)
+    ey, el = rel(y, yo), rel(lj, lo)
+    ey32, el32 = rel(y32, yo), rel(lj32, lo)
+    print(f"\nheadline net vs fp64 oracle: split-fp16 path y {ey:.2e} logJ {el:.2e} | fp32-product path y {ey32:.2e} logJ {el32:.2e}"
+          f" | CPU oracle in fp32: y {floor_y:.2e} logJ {floor_l:.2e}")
+    assert ey <= ty and el <= tl, (ey, ty, el, tl)
+    assert ey32 <= ty and el32 <= tl, (ey32, ty, el32, tl)
+
+
+def test_headline_network_full_size_split_vs_fp32_products():
+    """At the full 32^4 lattice the fp64 oracle is out of reach for 8 layers x several samples; the size-independent
+    statement is that the timed arithmetic (split-fp16 products) and exact fp32 MFMA products agree through all 8 layers
+    of bench.py's network -- both being within the bound of the test above of the fp64 oracle on the smaller lattice."""
+    import bench
+    lattice, B = (32, 32, 32, 32), 2
+    net_, cpl = bench.build_net(lattice, 8, 16, DEV, seed=2024)
+    g = torch.Generator(device=DEV).manual_seed(1234)
+    x = torch.randn((B,) + lattice, device=DEV, dtype=torch.float32, generator=g)
+    with torch.no_grad():
+        y, lj = net_(x)
+        assert _hip.load().nf_conv_last_path() == 3
+        with _hip.options(split16=False):
+            y32, lj32 = net_(x)
+            assert _hip.load().nf_conv_last_path() != 3
+        assert _hip.load().nf_get_option(_hip.OPT_SPLIT16) == 1
+    ey, el = rel(y, y32), rel(lj, lj32)
+    print(f"\n32^4, 8 layers: split-fp16 vs fp32 products: y {ey:.2e} logJ {el:.2e}")
+    assert ey <= 2e-5 and el <= 1e-5, (ey, el)
+    # one layer of the same network at full size against the fp64 oracle (1 sample: ~3 s of CPU)
+    xa, xf = cpl.mask.purify(x[:1], 0), cpl.mask.purify(x[:1], 1)
+    with torch.no_grad():
+        y1, l1 = cpl._fused_atom(False, xa, xf, 0, cpl.nets[0], 0)
+    nets = _oracle_nets(cpl, torch.float64)
+    out = nets[0](xf.double().cpu().unsqueeze(1))
+    yo, lo = O.rqs_coupling_atom(xa.double().cpu(), out, O.channel_mask(lattice, 0), log0=0,
+                                 xlim=(-5.0, 5.0), ylim=(-5.0, 5.0), extrap={'left': 'linear', 'right': 'linear'})
+    assert rel(y1, yo) <= 1e-5 and rel(l1, lo) <= 1e-5, (rel(y1, yo), rel(l1, lo))
+
+
+def test_bench_self_launch_two_ranks_rehearsal():
+    """`python bench.py --gpus 2` with no launcher: the parent starts two ranks itself (before any GPU call of its own) and
+    rank 0 prints ONE line with n_gpus 2, a weak and a strong leg.  NF_BENCH_REHEARSAL=1: both ranks share cuda:0 and meet
+    over gloo -- the code path of the 8-GPU run (RCCL there), on the one-GPU box."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["NF_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
+                        "--lattice", "4,4,4,32", "--layers", "2", "--kernel-reps", "3"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 16
+    assert line["strong"]["global_batch"] == 8 and line["strong"]["batch_per_gpu"] == 4 and line["strong"]["value"] > 0
+    assert line["value"] > 0 and line["value_fp32_products"] > 0 and line["selfcheck"]["split16_kernels_ran"]
+    assert "cpu_baseline" not in line          # rank 0 at N = 1 only

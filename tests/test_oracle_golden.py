@@ -194,3 +194,33 @@ def test_survey_appendix_b_known_answers():
     assert np.allclose(y.ravel().numpy(), ye, atol=5e-5)
     assert np.allclose(g.ravel().numpy(), ge, atol=5e-5)
     assert abs(float(O.softplus_ln2(torch.zeros(1).double())) - 1.0) < 1e-15
+
+
+def test_reference_fp32_fixture_covers_every_case_and_matches_oracle_fp32(golden):
+    """tests/golden/ref_fp32.npz (the reference run in float32 on the goldens' inputs, make_golden_fp32.py) is what the GPU
+    tests take their loosened fp32 bounds from.  (1) it has an entry for every case and quantity; (2) the CPU oracle run
+    in float32 lands within a small factor of the reference's own float32 error on the forward map -- so the oracle in
+    float32 is a fair stand-in floor for GPU tests whose inputs have no reference fixture."""
+    import os
+    r = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_fp32.npz"))
+    z = golden("atoms")
+    rel = lambda a, b: float((T(a).double() - T(b).double()).abs().max()) / max(1.0, float(T(b).double().abs().max()))
+    worst = 0.0
+    for tag in atom_cases():
+        for key in ("y", "logJ", "grad_x", "grad_out", "xhat", "logJ_rt"):
+            assert f"atoms/{tag}/{key}" in r.files
+        fn, opts = atom_fn(tag)
+        opts = dict(opts)
+        if tag.startswith("rqs_fixedx"):
+            opts["knots_x"] = T(z[f"{tag}/knots_x"]).float()
+        shape, parity = tuple(int(v) for v in z[f"{tag}/shape"]), int(z[f"{tag}/parity"])
+        g32 = lambda k: T(z[f"{tag}/{k}"]).float()
+        y, lj = fn(g32("x_active"), g32("out"), O.channel_mask(shape, parity, dtype=torch.float32), log0=g32("log0"), **opts)
+        for key, ours in (("y", y), ("logJ", lj)):
+            e_ref, e_or = rel(r[f"atoms/{tag}/{key}"], z[f"{tag}/{key}"]), rel(ours, z[f"{tag}/{key}"])
+            worst = max(worst, e_or / max(e_ref, 1e-6))
+    assert worst <= 4.0, worst
+    for fam, name in (("distconv", "distconv"), ("blocks", "blocks")):
+        zz = golden(name)
+        for tag in [str(c) for c in zz["_cases"]]:
+            assert f"{fam}/{tag}/y" in r.files and f"{fam}/{tag}/logJ" in r.files and f"{fam}/{tag}/grad_x" in r.files
