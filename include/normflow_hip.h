@@ -286,6 +286,18 @@ int nf_normal_logprob(const void *x, const void *loc, const void *scale, void *l
                       void *workspace, size_t workspace_bytes, int dtype, void *stream);
 int nf_normal_logprob_vjp(const void *x, const void *loc, const void *scale, const void *grad_logp,
                           void *grad_x, int64_t B, int64_t V, int dtype, void *stream);
+/* nf_normal_sample: Prior.sample_ for a NormalPrior (src/prior/prior.py:26-29 with :30-36 and :92-101) in ONE launch:
+ * x[b, i] = loc[i] + scale[i] z[b, i] with z standard normal, and logr[b] = sum_i [-z^2/2 - log scale[i] - log sqrt(2 pi)]
+ * accumulated from the z still in registers (the reference draws, then re-reads the field for log_prob, then sums).
+ * Generator: Philox4x32-10 (Salmon et al., SC'11; the Random123 / cuRAND / torch generator), counter-based and stateless:
+ *   group q = i / 4 (float32: four normals per call) or i / 2 (float64: two), g = b * ceil(V / per) + q,
+ *   counter = (lo32 g, hi32 g, lo32 offset, hi32 offset), key = (lo32 seed, hi32 seed), outputs r0..r3;
+ *   float32: (z0, z1) = rho (cos, sin)(2 pi u2) with u1 = (r0 + 1) 2^-32, u2 = r1 2^-32, rho = sqrt(-2 ln u1); (z2, z3) from (r2, r3);
+ *   float64: u1 = ((r0 << 21 ^ r1 >> 11) + 1) 2^-53, u2 = (r2 << 21 ^ r3 >> 11) 2^-53.
+ * The caller owns the stream position: advance `offset` by 1 per call (the host mirror takes seed and offset from torch's
+ * CUDA generator, so torch.manual_seed governs this kernel too).  loc / scale: (V) or NULL (0 / 1). */
+int nf_normal_sample(void *x, void *logr, const void *loc, const void *scale, int64_t B, int64_t V, uint64_t seed,
+                     uint64_t offset, void *workspace, size_t workspace_bytes, int dtype, void *stream);
 
 /* ---- VJP of the conv layer (K5) ---------------------------------------------------------------
  * grad_input is nf_conv_fwd itself applied to the pre-activation cotangent with the weights

@@ -63,6 +63,7 @@ PROTOTYPES = {
     "nf_phi4_action_vjp": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), _D, _D, _D, _I, _P]),
     "nf_normal_logprob": (_I, [_P, _P, _P, _P, _I64, _I64, _P, _SZ, _I, _P]),
     "nf_normal_logprob_vjp": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I, _P]),
+    "nf_normal_sample": (_I, [_P, _P, _P, _P, _I64, _I64, C.c_uint64, C.c_uint64, _P, _SZ, _I, _P]),
     "nf_act_vjp": (_I, [_P, _P, _P, _I64, _I, _I, _P]),
     "nf_conv_wgrad_cols": (_I, [_I, _I]),
     "nf_conv_wgrad": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I, _P]),
@@ -561,7 +562,7 @@ def _weights_fit_fp16(w):
             return False        # cannot synchronise here; the fp32 kernels are always valid
         if len(_UNIT_OK) > 256:
             _UNIT_OK.clear()
-        ok = bool(torch.isfinite(w).all()) and float(w.abs().max()) * SPLIT16_WEIGHT_SCALE < 3.0e4
+        ok = bool(torch.isfinite(w.detach()).all()) and float(w.detach().abs().max()) * SPLIT16_WEIGHT_SCALE < 3.0e4
         _UNIT_OK[key] = ok
     return ok
 
@@ -815,3 +816,28 @@ class NormalLogProbFn(torch.autograd.Function):
                                                 _ptr(gx[b0:b1]), b1 - b0, V, _dtype_code(x), _stream()),
                    "nf_normal_logprob_vjp")
         return gx, None, None
+
+
+def normal_sample(loc, scale, batch_size, shape, dtype, device, generator=None):
+    """(x (B, *shape), logr (B)) of a NormalPrior in one launch (nf_normal_sample).  Seed and stream offset come from
+    torch's CUDA generator of `device` (or `generator`), which is advanced by one Philox call's worth per launch -- so
+    torch.manual_seed(s) makes this kernel reproducible exactly as it does torch's own samplers."""
+    gen = generator if generator is not None else torch.cuda.default_generators[device.index if device.index is not None
+                                                                                  else torch.cuda.current_device()]
+    seed, offset = gen.initial_seed(), gen.get_offset()
+    gen.set_offset(offset + 4)            # torch keeps offsets in multiples of 4
+    V = 1
+    for n in shape:
+        V *= n
+    x = torch.empty((batch_size,) + tuple(shape), dtype=dtype, device=device)
+    logr = torch.empty(batch_size, dtype=dtype, device=device)
+    ws = _workspace(min(batch_size, MAX_B), V, device)
+    loc = None if loc is None else loc.to(device=device, dtype=dtype).contiguous()
+    scale = None if scale is None else scale.to(device=device, dtype=dtype).contiguous()
+    for b0 in range(0, batch_size, MAX_B):
+        b1 = min(batch_size, b0 + MAX_B)
+        # slabs of one call use disjoint counter ranges through the high word of the offset
+        _check(load().nf_normal_sample(_ptr(x[b0:b1]), _ptr(logr[b0:b1]), _ptr(loc), _ptr(scale), b1 - b0, V,
+                                       C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64((offset // 4) + ((b0 // MAX_B) << 40)),
+                                       _ptr(ws), ws.numel(), _dtype_code(x), _stream()), "nf_normal_sample")
+    return x, logr

@@ -70,10 +70,25 @@ class NormalPrior(Prior):
 
     _names = ("loc", "scale")
 
-    def __init__(self, loc=None, scale=None, shape=None, seed=None):
+    def __init__(self, loc=None, scale=None, shape=None, seed=None, torch_rng=False):
+        """`torch_rng=True` keeps torch.distributions' sampler (the reference's random stream on a given seed) and the
+        separate log_prob pass; the default on a HIP device is the fused Philox kernel: one launch emits x and log r."""
+        self._unit = shape is not None
         if shape is not None:
             loc, scale = torch.zeros(shape), torch.ones(shape)
         super().__init__(loc, scale, seed)
+        self.torch_rng = torch_rng
+
+    def sample_(self, batch_size=1):
+        """(x, log r) (prior.py:26-29): on a HIP device ONE kernel (nf_normal_sample) draws the field and accumulates its
+        log-density from the normals still in registers."""
+        loc = self.loc
+        if (not self.torch_rng and not self.propagate_density and loc.is_cuda
+                and loc.dtype in (torch.float32, torch.float64) and batch_size >= 1):
+            unit = self._unit
+            return _hip.normal_sample(None if unit else loc.reshape(-1), None if unit else self.scale.reshape(-1),
+                                      batch_size, self.shape, loc.dtype, loc.device)
+        return super().sample_(batch_size)
 
     loc = property(lambda self: self._p[0])
     scale = property(lambda self: self._p[1])

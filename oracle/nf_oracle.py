@@ -481,3 +481,71 @@ def normal_log_prob(x):
 def kl_loss(logq, logp):
     """Fitter.calc_kl_mean (src/_normflowcore.py:326-329)."""
     return (logq - logp).mean()
+
+
+# ------------------------------------------------------------------ prior sampling (SURVEY 8(f) 3)
+# The reference draws with torch.distributions.Normal.sample (src/prior/prior.py:26-29, 92-101) and then makes a second
+# pass for log_prob (:30-36).  Its random STREAM is whatever torch's generator gives (mt19937 on CPU, torch's own Philox
+# schedule on GPU) and is not part of the contract -- the distribution and the identity logr = log N(x) are.  The HIP
+# kernel (nf_normal_sample) uses Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
+# SC'11 -- the Random123 generator; absent from /root/reference, restated here from the published algorithm and pinned by
+# Random123's known-answer vectors in tests/test_oracle_golden.py) with a counter layout of its own, restated below so
+# that the kernel's draws can be checked number by number.
+PHILOX_M0, PHILOX_M1 = 0xD2511F53, 0xCD9E8D57
+PHILOX_W0, PHILOX_W1 = 0x9E3779B9, 0xBB67AE85
+
+
+def philox4x32_10(counter, key):
+    """counter: (..., 4) uint32, key: (..., 2) uint32 -> (..., 4) uint32 (numpy; 10 rounds)."""
+    import numpy as np
+    c = [np.asarray(counter[..., i], dtype=np.uint64) for i in range(4)]
+    k0 = np.asarray(key[..., 0], dtype=np.uint64)
+    k1 = np.asarray(key[..., 1], dtype=np.uint64)
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(PHILOX_M0) * c[0]
+        p1 = np.uint64(PHILOX_M1) * c[2]
+        hi0, lo0 = p0 >> np.uint64(32), p0 & mask
+        hi1, lo1 = p1 >> np.uint64(32), p1 & mask
+        c = [hi1 ^ c[1] ^ k0, lo1, hi0 ^ c[3] ^ k1, lo0]
+        k0 = (k0 + np.uint64(PHILOX_W0)) & mask
+        k1 = (k1 + np.uint64(PHILOX_W1)) & mask
+    return np.stack([v.astype(np.uint32) for v in c], axis=-1)
+
+
+def normal_prior_sample(seed, offset, B, V, loc=None, scale=None, dtype=torch.float32):
+    """(x (B, V), logr (B)) exactly as nf_normal_sample lays its draws out (include/normflow_hip.h):
+    group q = element index // 4 of sample b (float32: 4 normals per Philox call) or // 2 (float64: 2 per call);
+    counter = (lo32(g), hi32(g), lo32(offset), hi32(offset)) with g = b * ngroups + q, key = (lo32(seed), hi32(seed));
+    Box-Muller: float32 u1 = (r + 1) 2^-32, u2 = r' 2^-32 from (r0, r1) -> (z0, z1) = rho (cos, sin)(2 pi u2) and (r2, r3) ->
+    (z2, z3); float64 u1 = ((r0 << 21 ^ r1 >> 11) + 1) 2^-53, u2 likewise from (r2, r3) without the + 1.
+    x = loc + scale z;  logr = sum_x [-z^2/2 - log scale - log sqrt(2 pi)]."""
+    import numpy as np
+    per = 4 if dtype == torch.float32 else 2
+    ngroups = (V + per - 1) // per
+    g = (np.arange(B, dtype=np.uint64)[:, None] * np.uint64(ngroups) + np.arange(ngroups, dtype=np.uint64)[None, :])
+    ctr = np.stack([(g & np.uint64(0xFFFFFFFF)), (g >> np.uint64(32)),
+                    np.full_like(g, offset & 0xFFFFFFFF), np.full_like(g, (offset >> 32) & 0xFFFFFFFF)], axis=-1).astype(np.uint32)
+    key = np.broadcast_to(np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32), g.shape + (2,))
+    r = philox4x32_10(ctr, key).astype(np.float64)
+    if dtype == torch.float32:
+        def bm(ra, rb):
+            u1, u2 = (ra + 1.0) * 2.0 ** -32, rb * 2.0 ** -32
+            rho = np.sqrt(-2.0 * np.log(u1))
+            return rho * np.cos(2 * np.pi * u2), rho * np.sin(2 * np.pi * u2)
+        z0, z1 = bm(r[..., 0], r[..., 1])
+        z2, z3 = bm(r[..., 2], r[..., 3])
+        z = np.stack([z0, z1, z2, z3], axis=-1)
+    else:
+        ri = philox4x32_10(ctr, key).astype(np.uint64)
+        a = ((ri[..., 0] << np.uint64(21)) ^ (ri[..., 1] >> np.uint64(11))).astype(np.float64)
+        b = ((ri[..., 2] << np.uint64(21)) ^ (ri[..., 3] >> np.uint64(11))).astype(np.float64)
+        u1, u2 = (a + 1.0) * 2.0 ** -53, b * 2.0 ** -53
+        rho = np.sqrt(-2.0 * np.log(u1))
+        z = np.stack([rho * np.cos(2 * np.pi * u2), rho * np.sin(2 * np.pi * u2)], axis=-1)
+    z = torch.from_numpy(z.reshape(B, ngroups * per)[:, :V]).to(torch.float64)
+    loc = torch.zeros(V, dtype=torch.float64) if loc is None else loc.double().reshape(-1)
+    scale = torch.ones(V, dtype=torch.float64) if scale is None else scale.double().reshape(-1)
+    x = loc + scale * z
+    logr = (-0.5 * z * z - torch.log(scale) - 0.5 * math.log(2 * math.pi)).sum(dim=1)
+    return x.to(dtype), logr.to(dtype)

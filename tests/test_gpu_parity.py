@@ -1275,3 +1275,70 @@ def test_bench_self_launch_two_ranks_rehearsal():
     assert line["strong"]["global_batch"] == 8 and line["strong"]["batch_per_gpu"] == 4 and line["strong"]["value"] > 0
     assert line["value"] > 0 and line["value_fp32_products"] > 0 and line["selfcheck"]["split16_kernels_ran"]
     assert "cpu_baseline" not in line          # rank 0 at N = 1 only
+
+
+# -------------------------------------------------- the prior as one Philox kernel
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("B,shape,affine", [(3, (4, 4, 2, 6), False), (5, (7,), True), (2, (6, 5), True), (1, (1,), False),
+                                            (4, (16, 16, 16), False)])
+def test_philox_prior_kernel_vs_oracle(B, shape, affine, dtype):
+    """nf_normal_sample through the C ABI against the oracle's restatement of the same counter layout, number by number
+    (float32: the Box-Muller transcendentals are hardware log / sin / cos, 2e-5 absolute on O(1) draws; float64 1e-10),
+    and logr against both the oracle and the density of the drawn field."""
+    from normflow__amd.prior import NormalPrior
+    V = int(np.prod(shape))
+    if affine:
+        g = torch.Generator(device='cpu').manual_seed(3)
+        loc = torch.randn(shape, generator=g, device='cpu').to(DEV, dtype)
+        scale = (0.5 + torch.rand(shape, generator=g, device='cpu')).to(DEV, dtype)
+        prior = NormalPrior(loc=loc, scale=scale)
+    else:
+        loc = scale = None
+        prior = NormalPrior(shape=shape)
+        prior.to(device=DEV, dtype=dtype)
+    torch.manual_seed(4242)
+    gen = torch.cuda.default_generators[DEV.index]
+    seed, off = gen.initial_seed(), gen.get_offset()
+    x, logr = prior.sample_(B)
+    assert gen.get_offset() == off + 4 and x.shape == (B,) + shape and logr.shape == (B,) and x.dtype == dtype
+    xo, lo = O.normal_prior_sample(seed, off // 4, B, V, loc=None if loc is None else loc.cpu(),
+                                   scale=None if scale is None else scale.cpu(), dtype=torch.float64)
+    tol = 2e-5 if dtype == torch.float32 else 1e-10
+    assert float((x.double().cpu().reshape(B, V) - xo).abs().max()) <= tol * max(1.0, float(xo.abs().max()))
+    assert rel(logr, lo) <= (1e-5 if dtype == torch.float32 else 1e-10)
+    assert rel(logr, prior.log_prob(x)) <= (1e-5 if dtype == torch.float32 else 1e-10)      # logr IS the density of x
+    torch.manual_seed(4242)
+    x2, _ = prior.sample_(B)
+    x3, _ = prior.sample_(B)
+    assert torch.equal(x, x2) and not torch.equal(x2, x3)          # torch.manual_seed governs the kernel; the stream advances
+    prior.torch_rng = True                                          # the reference's sampler stays available
+    torch.manual_seed(7)
+    xt, lt = prior.sample_(B)
+    torch.manual_seed(7)
+    want = torch.normal(prior.loc.expand((B,) + shape), prior.scale.expand((B,) + shape))
+    assert torch.equal(xt, want) and rel(lt, prior.log_prob(xt)) <= 1e-6
+
+
+def test_philox_prior_statistics():
+    """10^6 draws per call: moments and a Kolmogorov-Smirnov test against the normal CDF; independence across samples
+    and across calls (correlation of consecutive calls); a 32^4 batch fills every site."""
+    from scipy import stats
+    from normflow__amd.prior import NormalPrior
+    prior = NormalPrior(shape=(1000,))
+    prior.to(device=DEV, dtype=torch.float32)
+    torch.manual_seed(99)
+    x, logr = prior.sample_(1000)
+    z = x.double().cpu().numpy().ravel()
+    assert abs(z.mean()) < 4e-3 and abs(z.std() - 1) < 3e-3
+    assert abs(stats.skew(z)) < 0.01 and abs(stats.kurtosis(z)) < 0.02
+    assert stats.kstest(z, "norm").pvalue > 1e-3
+    assert abs(np.corrcoef(z[:-1], z[1:])[0, 1]) < 4e-3                       # neighbours in a group / across groups
+    x2, _ = prior.sample_(1000)
+    assert abs(np.corrcoef(z, x2.double().cpu().numpy().ravel())[0, 1]) < 4e-3
+    assert z.max() > 4.0 and z.min() < -4.0                                    # the tails are there
+    big = NormalPrior(shape=(32, 32, 32, 32))
+    big.to(device=DEV, dtype=torch.float32)
+    xb, lb = big.sample_(3)
+    assert bool(torch.isfinite(xb).all()) and float((xb == 0).float().mean()) < 1e-6
+    assert rel(lb, big.log_prob(xb)) <= 1e-5
+    assert abs(float(xb.mean())) < 2e-3 and abs(float(xb.std()) - 1) < 2e-3

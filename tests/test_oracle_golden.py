@@ -224,3 +224,24 @@ def test_reference_fp32_fixture_covers_every_case_and_matches_oracle_fp32(golden
         zz = golden(name)
         for tag in [str(c) for c in zz["_cases"]]:
             assert f"{fam}/{tag}/y" in r.files and f"{fam}/{tag}/logJ" in r.files and f"{fam}/{tag}/grad_x" in r.files
+
+
+def test_philox_known_answers_and_prior_sampler_oracle():
+    """The oracle's Philox4x32-10 against Random123's published known-answer vectors (kat_vectors: three (counter, key) ->
+    output triples), then the sampler restatement built on it: moments of the draws and logr = log N(x) exactly."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = O.philox4x32_10(np.array(ctr, dtype=np.uint32), np.array(key, dtype=np.uint32))
+        assert tuple(int(v) for v in got) == want
+    for dt in (torch.float32, torch.float64):
+        x, logr = O.normal_prior_sample(77, 3, 4000, 37, dtype=dt)
+        assert abs(float(x.double().mean())) < 0.01 and abs(float(x.double().std()) - 1.0) < 0.01
+        close(logr.double(), O.normal_log_prob(x.double()), 1e-5 if dt == torch.float32 else 1e-12)
+    loc, scale = torch.linspace(-1, 1, 10), torch.linspace(0.5, 2.0, 10)
+    x, logr = O.normal_prior_sample(5, 0, 20000, 10, loc=loc, scale=scale, dtype=torch.float64)
+    assert float((x.mean(dim=0) - loc).abs().max()) < 0.05 and float((x.std(dim=0) / scale - 1).abs().max()) < 0.03
+    ref = torch.distributions.Normal(loc.double(), scale.double()).log_prob(x).sum(dim=1)
+    close(logr, ref, 1e-12)

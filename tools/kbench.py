@@ -1,0 +1,22 @@
+"""Time the three kernels of one coupling layer of the bench network at the pipeline's slab (HIP events), one line each.
+    python tools/kbench.py [--batch 256] [--reps 5]"""
+import argparse, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("NORMFLOW_AMD_KEEP_TORCH_DEFAULTS", "1")
+import torch
+import bench
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--lattice", type=str, default="32,32,32,32")
+ap.add_argument("--tag", type=str, default="")
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+lattice = tuple(int(s) for s in a.lattice.split(","))
+net_, cpl = bench.build_net(lattice, 2, 16, dev, seed=2024)
+ft = bench.time_fused_last_layer(cpl, lattice, 16, dev, a.reps, a.batch)
+oth = bench.time_hidden_layers(cpl, lattice, dev, a.reps, a.batch)
+print(f"[kbench {a.tag}] slab {ft['slab']}  K5h {1e3*ft['seconds']:.3f} ms  K5g {oth[1]['launch_ms']:.3f} ms  K5c {oth[0]['launch_ms']:.3f} ms  "
+      f"sum {1e3*ft['seconds'] + oth[1]['launch_ms'] + oth[0]['launch_ms']:.3f} ms", flush=True)
