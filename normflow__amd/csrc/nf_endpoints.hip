@@ -179,9 +179,9 @@ __global__ __launch_bounds__(kBlock) void normal_sample_kernel(SampleArgs A) {
       for (int h = 0; h < 2; ++h) {
         const float u1 = (float(c[2 * h] >> 8) + (float(c[2 * h] & 255u) + 1.0f) * 0.00390625f) * 5.9604644775390625e-08f;   // (r + 1) 2^-32, no rounding to 0 or above 1
         const float u2 = float(c[2 * h + 1]) * 2.3283064365386963e-10f;
-        const float rho = __builtin_sqrtf(-2.0f * __logf(u1 > 1.0f ? 1.0f : u1));
+        const float rho = __builtin_sqrtf(-2.0f * logf(u1 > 1.0f ? 1.0f : u1));
         float sn, cs;
-        __sincosf(6.283185307179586f * (u2 >= 1.0f ? 0.0f : u2), &sn, &cs);
+        sincospif(2.0f * u2, &sn, &cs);        // exact range reduction (the argument is in half-turns); the kernel stays near its HBM floor
         z[2 * h] = rho * cs;
         z[2 * h + 1] = rho * sn;
       }

@@ -544,8 +544,8 @@ def normal_prior_sample(seed, offset, B, V, loc=None, scale=None, dtype=torch.fl
         rho = np.sqrt(-2.0 * np.log(u1))
         z = np.stack([rho * np.cos(2 * np.pi * u2), rho * np.sin(2 * np.pi * u2)], axis=-1)
     z = torch.from_numpy(z.reshape(B, ngroups * per)[:, :V]).to(torch.float64)
-    loc = torch.zeros(V, dtype=torch.float64) if loc is None else loc.double().reshape(-1)
-    scale = torch.ones(V, dtype=torch.float64) if scale is None else scale.double().reshape(-1)
+    loc = torch.zeros(V, dtype=torch.float64, device='cpu') if loc is None else loc.double().reshape(-1)
+    scale = torch.ones(V, dtype=torch.float64, device='cpu') if scale is None else scale.double().reshape(-1)
     x = loc + scale * z
     logr = (-0.5 * z * z - torch.log(scale) - 0.5 * math.log(2 * math.pi)).sum(dim=1)
     return x.to(dtype), logr.to(dtype)

@@ -1302,7 +1302,8 @@ def test_philox_prior_kernel_vs_oracle(B, shape, affine, dtype):
     x, logr = prior.sample_(B)
     assert gen.get_offset() == off + 4 and x.shape == (B,) + shape and logr.shape == (B,) and x.dtype == dtype
     xo, lo = O.normal_prior_sample(seed, off // 4, B, V, loc=None if loc is None else loc.cpu(),
-                                   scale=None if scale is None else scale.cpu(), dtype=torch.float64)
+                                   scale=None if scale is None else scale.cpu(), dtype=dtype)     # dtype selects the draw layout
+    xo, lo = xo.double(), lo.double()
     tol = 2e-5 if dtype == torch.float32 else 1e-10
     assert float((x.double().cpu().reshape(B, V) - xo).abs().max()) <= tol * max(1.0, float(xo.abs().max()))
     assert rel(logr, lo) <= (1e-5 if dtype == torch.float32 else 1e-10)
