@@ -206,9 +206,14 @@ int nf_conv_two_site(int cout, int compact, int l3, int k3);
 int nf_conv_cin_pad(int cin);
 int nf_conv_ntiles(int cout);
 int nf_conv_packed_steps(int cin, int ntaps);
-/* `compact`: 0 = (B, cout, V) planes; 1 = pair-compact (B, cout, V/2), active sites only; NF_OUT_SPLIT16 (2) = full
- * lattice as fp16 (hi, lo) pairs, channel-last: (B, V, 16) halfs -- 8-output-channel two-site layers feeding
- * nf_conv_rqs(flags = NF_CONV_UNIT_INPUT | NF_CONV_SPLIT16_INPUT); same bytes as the fp32 planes. */
+/* `compact`: 0 = (B, cout, V) planes; 1 = pair-compact (B, cout, V/2), active sites only; NF_OUT_SPLIT16 (2) = the full
+ * lattice as the fp16 (hi, lo) PAIR TENSOR of 8-output-channel two-site layers -- what nf_conv_fwd_split16 reads and writes
+ * and nf_conv_rqs(flags = NF_CONV_UNIT_INPUT | NF_CONV_SPLIT16_INPUT) reads; same bytes as the 8 fp32 planes, (B, V, 16) halfs:
+ *   per lattice row (the L3 sites of the fastest axis; rows in row-major order of the other axes) L3*32 bytes =
+ *     [hi | lo][even sites | odd sites][L3/2 slots][8 channels], hi = fp16(a), lo = fp16(a - hi);
+ *   the even block holds site 2s in slot s, the odd block site 2s - 1 (mod L3) in slot s.
+ * A row is thus a contiguous image that LDS-DMA copies as it stands (L3 = 32: exactly one 1 KiB wave-instruction), every
+ * 16-byte entry is one k-group of an MFMA A fragment, and a tap-by-tap read of the image is free of LDS bank conflicts. */
 enum { NF_OUT_SPLIT16 = 2 };
 int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, void *out, int64_t B,
                 const int32_t *lattice, const int32_t *ksize, int cin, int cout, int act,
@@ -231,8 +236,9 @@ int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, void *out, 
 enum { NF_WLAYOUT_FRAGMENT = 0, NF_WLAYOUT_ROWPACK = 1, NF_WLAYOUT_SPLIT16 = 2 };
 int nf_conv_weight_layout(const int32_t *lattice, const int32_t *ksize, int cin, int cout, int compact,
                           int fused, int dtype);
-/* A hidden 8 -> 8 layer whose input AND output are the fp16 (hi, lo) pair format (nf_conv_h.hip, conv_g_kernel: two-site
- * columns, one v_mfma_f32_16x16x32_f16 slice per kernel row, three fp16 products per fp32 product).
+/* A hidden 8 -> 8 layer whose input AND output are the fp16 (hi, lo) pair tensor above (nf_conv_g.hip: two-site columns,
+ * one v_mfma_f32_16x16x32_f16 slice per kernel row, three fp16 products per fp32 product; persistent workgroups marching
+ * 2 x 2 columns of lattice rows through an LDS ring filled by LDS-DMA).  in16 and out16 must not overlap.
  *   in16, out16: (B, V, 16) halfs; wsplit: [kernel row (27)][hi|lo][64 lanes][8] halfs -- lane 16*g + n holds, for column
  *   n = 8*shift + co, the 8 input channels of tap (g - shift) of that kernel row (zero outside 0..2), scaled by 2^10
  *   and split as in NF_WLAYOUT_SPLIT16; bias (8) fp32 or NULL; act must keep |out| <= 1 (tanh, logistic).

@@ -505,23 +505,40 @@ def pack_conv_weight_split16_two_site(w):
     return out.contiguous()
 
 
+def _split16_site_index(L3, device):
+    """idx[par, slot] = the site x3 of a lattice row stored in slot `slot` of parity block `par` of the fp16 pair layout
+    (include/normflow_hip.h, NF_OUT_SPLIT16): even sites in order, odd sites rotated by one slot (slot s holds site 2s-1)."""
+    slot = torch.arange(L3 // 2, device=device)
+    return torch.stack((2 * slot, (2 * slot - 1) % L3))
+
+
 def to_split16(h):
-    """(B, 8, *L) fp32 hidden activations (|h| <= 1) -> the (B, V, 16) fp16 pair tensor the split-fp16 kernels exchange
-    (per site hi[8] | lo[8], hi = fp16(h), lo = fp16(h - hi)).  Host-side helper for tests and benches: in the pipeline
-    the producing kernel's epilogue writes this format itself."""
+    """(B, 8, *L) fp32 hidden activations (|h| <= 1) -> the fp16 pair tensor the split-fp16 kernels exchange, shape
+    (B, V, 16) halfs = per lattice row (fastest axis, L3 sites) [hi | lo][even sites | odd sites][L3/2 slots][8 channels]
+    with hi = fp16(h), lo = fp16(h - hi) (layout: include/normflow_hip.h, NF_OUT_SPLIT16).  Host-side helper for tests and
+    benches: in the pipeline the producing kernel's epilogue writes this format itself."""
     B, Cc = h.shape[:2]
-    if Cc != 8:
-        raise NormflowHipError("to_split16: 8 channels expected")
-    hp = h.reshape(B, 8, -1).permute(0, 2, 1).float()
-    hi = hp.half()
-    return torch.cat((hi, (hp - hi.float()).half()), dim=2).contiguous()
+    L3 = h.shape[-1]
+    if Cc != 8 or L3 % 2:
+        raise NormflowHipError("to_split16: 8 channels and an even fastest axis expected")
+    hp = h.reshape(B, 8, -1, L3).float()
+    idx = _split16_site_index(L3, h.device)                           # (2, L3/2)
+    g = hp[..., idx].permute(0, 2, 3, 4, 1)                           # (B, R, par, slot, channel)
+    hi = g.half()
+    lo = (g - hi.float()).half()
+    return torch.stack((hi, lo), dim=2).reshape(B, -1, 16).contiguous()
 
 
 def from_split16(h16, lattice):
     """Inverse of to_split16 up to the split's rounding: (B, V, 16) halfs -> (B, 8, *L) fp32 (hi + lo)."""
     B = h16.shape[0]
-    v = h16[:, :, :8].float() + h16[:, :, 8:].float()
-    return v.permute(0, 2, 1).reshape((B, 8) + tuple(lattice)).contiguous()
+    L3 = lattice[-1]
+    t = h16.reshape(B, -1, 2, 2, L3 // 2, 8).float()
+    v = t[:, :, 0] + t[:, :, 1]                                       # (B, R, par, slot, channel)
+    idx = _split16_site_index(L3, h16.device)
+    out = torch.empty((B, v.shape[1], L3, 8), dtype=torch.float32, device=h16.device)
+    out[:, :, idx.reshape(-1)] = v.reshape(B, v.shape[1], L3, 8)
+    return out.permute(0, 3, 1, 2).reshape((B, 8) + tuple(lattice)).contiguous()
 
 
 def conv_layer_split16(h16, weight, bias, act, lattice):

@@ -71,6 +71,18 @@ struct ConvArgs {
   int wide_no, wide_llpr;   // nf_conv_pipe.hip wide staging: row blocks per wave (0 = narrow), log2(lanes per row)
 };
 
+// The fp16 (hi, lo) pair tensor exchanged by the split-fp16 kernels (include/normflow_hip.h, NF_OUT_SPLIT16) is row-major:
+// a lattice row (L3 sites of the fastest axis) is L3*32 bytes = [hi | lo][even sites | odd sites][L3/2 slots][8 channels]
+// halfs; the even block holds site 2s in slot s, the odd block site 2s-1 (mod L3) in slot s (the one-slot rotation keeps
+// the four lane groups of a ds_read_b128 on different LDS banks when a row image is read tap by tap).  Byte offset of a
+// site's hi entry inside its row; its lo entry is L3*16 bytes further.
+__host__ __device__ __forceinline__ int pair_row_offset(int x3, int L3) {
+  const int par = x3 & 1;
+  int slot = (x3 + par) >> 1;
+  slot = slot >= (L3 >> 1) ? slot - (L3 >> 1) : slot;
+  return par * (L3 * 8) + slot * 16;
+}
+
 // tanh on the hardware exp/rcp: (1 - t) / (1 + t), t = exp(-2|v|); absolute error ~1e-7 (the fp32 rounding of an
 // O(1) activation), ~8 instructions where ocml's tanhf takes ~40 -- it was most of the 8->8 layer's epilogue.
 __device__ __forceinline__ float fast_tanh(float v) {
@@ -255,7 +267,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, const int (&o)[
         lds_barrier();
         if (A.out_split16) {
           // the consumer is the split-fp16 kernel (nf_conv_h.hip): hand it every site's 8 channels already split
-          // into fp16 (hi, lo) pairs, channel-last -- one conversion per site here instead of one per halo copy there
+          // into fp16 (hi, lo) pairs in the row-major pair layout (pair_row_offset) -- one conversion per site here
+          // instead of one per halo copy there
           typedef _Float16 h8 __attribute__((ext_vector_type(8)));
           unsigned char *ob = reinterpret_cast<unsigned char *>(out_b);
           for (int t = threadIdx.x; t < rows * b3; t += kBlock) {
@@ -275,9 +288,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, const int (&o)[
             zr >>= A.lbox[1];
             const int x0 = o[0] + zr, x1 = o[1] + z1, x2 = o[2] + z2;
             if (x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2] && x3 < A.L[3]) {
-              unsigned char *d = ob + (((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + x3) * 32;
+              unsigned char *d = ob + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * (A.L[3] * 32) + pair_row_offset(x3, A.L[3]);
               *reinterpret_cast<h8 *>(d) = hi;
-              *reinterpret_cast<h8 *>(d + 16) = lo;
+              *reinterpret_cast<h8 *>(d + A.L[3] * 16) = lo;
             }
           }
           return;

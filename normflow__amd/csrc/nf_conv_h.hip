@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   auto stage = [&](int b, const int (&o)[4], unsigned char *imgH) {
     const int myoff = row_offsets(o);
     if (pre) {
-      const unsigned char *__restrict__ src = static_cast<const unsigned char *>(A.in) + (int64_t(b) * A.V + xs) * 32;
+      const unsigned char *__restrict__ src = static_cast<const unsigned char *>(A.in) + int64_t(b) * A.V * 32 + pair_row_offset(xs, L3);
       f16x8 h0[PB], l0[PB], h1[PB], l1[PB];
       auto issue = [&](f16x8 (&h)[PB], f16x8 (&l)[PB], int p0) {
 #pragma unroll
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
           const int ob = __builtin_amdgcn_readlane(myoff, 2 * (p0 + j) + 1);
           const unsigned char *q = src + int64_t(rs ? ob : oa) * 32;
           h[j] = *reinterpret_cast<const f16x8 *>(q);
-          l[j] = *reinterpret_cast<const f16x8 *>(q + 16);
+          l[j] = *reinterpret_cast<const f16x8 *>(q + L3 * 16);
         }
       };
       auto commit = [&](const f16x8 (&h)[PB], const f16x8 (&l)[PB], int p0) {
@@ -409,6 +409,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   // after item m+1 has been committed, committed after the epilogue of the following iteration -- so the copy never
   // waits for memory.  (fp32 input keeps the in-iteration staging above: it is the fallback, not the pipeline's path.)
   f16x8 qh[NROW / 2], ql[NROW / 2];
+  const unsigned xoff = unsigned(pair_row_offset(xs, L3));
   auto issue_item = [&](int b, const int (&o)[4]) {
     const int myoff = row_offsets(o);
     // uniform 64-bit base + 32-bit per-lane byte offset (a sample is V*32 < 2^32 bytes): scalar-base addressing
@@ -417,9 +418,9 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     for (int i = 0; i < NROW / 2; ++i) {
       const unsigned oa = unsigned(__builtin_amdgcn_readlane(myoff, 2 * i));
       const unsigned ob = unsigned(__builtin_amdgcn_readlane(myoff, 2 * i + 1));
-      const unsigned voff = ((rs ? ob : oa) + unsigned(xs)) * 32u;
+      const unsigned voff = (rs ? ob : oa) * 32u + xoff;            // row start (row-major pair layout) + this lane's site
       qh[i] = *reinterpret_cast<const f16x8 *>(src + voff);
-      ql[i] = *reinterpret_cast<const f16x8 *>(src + voff + 16u);
+      ql[i] = *reinterpret_cast<const f16x8 *>(src + voff + unsigned(L3 * 16));
     }
   };
   // lane-constant part of the LDS address (row = 2i + rs); per pass only an immediate row offset is added
@@ -499,373 +500,4 @@ int launch_conv_h(const ConvArgs &A0, int64_t B, int64_t nboxes, int fuse, hipSt
 }
 
 
-// ---------------------------------------------------------------------------------------------------------
-// K5g: a hidden 8 -> 8 ConvAct layer between two split-fp16 consumers.  Input and output are the channel-last fp16
-// (hi, lo) pairs, 32 bytes per site.  Two-site columns (column n = 8*shift + co = channel co at site 2p + shift) make
-// the four fastest-axis taps -1..+2 of a site pair the four k-groups of ONE v_mfma_f32_16x16x32_f16: a kernel row
-// (j0, j1, j2) is exactly one K slice (4 taps x 8 channels), 27 slices in all, A[pair p][k-group g] = the 8 channels of
-// halo site 2p + g -- parity g & 1, entry p + (g >> 1) of the parity-split image: conflict-free reads with immediate
-// offsets.  Every wave keeps all 27 B fragment pairs (216 registers) and owns two of the box's eight site tiles (a
-// tile = one box row of 16 pairs), i.e. 27 x 2 x 3 = 162 MFMAs per item where the fp32 kernel issues 432 four times
-// slower ones: the layer turns from MFMA-bound into data movement (32 B in, 32 B out per site), so the structure is the
-// first layer's (conv_c1_kernel): persistent workgroups, an item's input loads parked in registers for a whole
-// iteration, output through an LDS transpose.
-// BZ2 = box extent along axis 2 (2 or 4): the 2x2x4x32 box halves the per-item overhead and cuts the halo re-reads from
-// 8.5x to 6.4x; its image does not fit LDS twice, so there is ONE image per workgroup and the item loop is
-//   compute(m) | barrier | commit image(m+1), store item m, issue loads(m+2) | barrier.
-template <int BZ2>
-struct GeoG {
-  static constexpr int H1 = 4, H2 = BZ2 + 2;                // (the fastest axis is spanned and periodic: wrapped by address, no halo sites)
-  static constexpr int NROW = 4 * H1 * H2;                  // halo rows
-  static constexpr int ROWB = 16 * 16;
-#ifndef NF_G_SKEW
-#define NF_G_SKEW 16      // one 16-byte slot: with it the four lane groups of a ds_read_b128 (lanes {0-3,12-15,20-27}, ...) touch 16 different slots (128 measured 2.5 % slower)
-#endif
-  static constexpr int SUB = NROW * ROWB + NF_G_SKEW;             // parity sub-image (+ bank skew)
-  static constexpr int IMG = 2 * SUB;                       // one fp16 image (hi or lo)
-  static constexpr int NTILE = 4 * BZ2;                     // site tiles (= box rows of 16 pairs)
-  static constexpr int TPW = NTILE / 4;                     // tiles per wave
-  static constexpr int SITES = 32 * NTILE;
-  static constexpr int CS = SITES + 8;                      // channel stride of the output transpose (floats)
-  static constexpr int RPW = NROW / 4;                      // halo rows staged per wave
-  static constexpr int NPASS = RPW / 2;                     // two rows per pass
-  static constexpr int LDS = 2 * IMG + 2 * 8 * CS * 4;      // one image (hi, lo) + two output transposes (item m's is stored while item m+1 multiplies)
-  static __host__ __device__ constexpr int rowidx(int r) { return ((r / 9) * H1 + (r / 3) % 3) * H2 + r % 3; }
-};
-
-template <int BZ2>
-__global__ __launch_bounds__(256, 1) void conv_g_kernel(ConvArgs A) {
-  typedef GeoG<BZ2> G;
-  using h::kInvWScale;
-  extern __shared__ __align__(16) unsigned char smem_g[];
-  unsigned char *imgH = smem_g, *imgL = smem_g + G::IMG;
-  float *ot = reinterpret_cast<float *>(smem_g + 2 * G::IMG);
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int g = lane >> 4;
-  // XCD x (= blockIdx & 7: consecutive workgroups go to consecutive XCDs) owns a contiguous eighth of the items and walks it
-  // nb workgroups at a time: what one step's boxes share with the next step's (their halos) is still in that XCD's L2
-  // (measured on 2x2x4x32 boxes: 17.8 GB per 256-sample launch through the fabric against 21.5 GB with the XCDs taking turns
-  // step by step, which is the better order for K5h's 2x2x2x32 boxes)
-  const int nb = gridDim.x >> 3;
-  const int chunk = int((A.nitems + 8 * nb - 1) / (8 * nb)) * nb;
-  const int vb = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-  const int vend = (blockIdx.x & 7) * chunk + chunk < A.nitems ? (blockIdx.x & 7) * chunk + chunk : int(A.nitems);
-  if (vb >= vend) return;
-  const int n_my = (vend - vb + nb - 1) / nb;
-  auto decode = [&](int it, int &b, int (&o)[4]) {
-    b = it / A.nboxes;
-    int bid = it - b * A.nboxes;
-#pragma unroll
-    for (int mu = 3; mu >= 0; --mu) {
-      o[mu] = (bid % A.nbox[mu]) * A.box[mu];
-      bid /= A.nbox[mu];
-    }
-  };
-  int sb_, sc_[4];                  // mixed-radix digits of the item stride nb: no divisions in the loop
-  {
-    int so_[4];
-    decode(nb, sb_, so_);
-#pragma unroll
-    for (int mu = 0; mu < 4; ++mu) sc_[mu] = so_[mu];
-  }
-  auto advance = [&](int &b, int (&o)[4]) {
-    int carry = 0;
-#pragma unroll
-    for (int mu = 3; mu >= 0; --mu) {
-      o[mu] += sc_[mu] + carry * A.box[mu];
-      const int lim = A.nbox[mu] * A.box[mu];
-      carry = o[mu] >= lim ? 1 : 0;
-      o[mu] -= carry ? lim : 0;
-    }
-    b += sb_ + carry;
-  };
-
-  // ---- weights: all 27 slices, hi and lo
-  const f16x8 *__restrict__ wsp = static_cast<const f16x8 *>(A.wfrag) + lane;
-  f16x8 bh[27], bl[27];
-#pragma unroll
-  for (int r = 0; r < 27; ++r) {
-    bh[r] = wsp[(2 * r) * 64];
-    bl[r] = wsp[(2 * r + 1) * 64];
-  }
-  const int col = lane & 15, co = col & 7, shift = col >> 3;
-  const float bv = (A.bias && co < A.cout) ? static_cast<const float *>(A.bias)[co] : 0.f;
-  // ---- A reads: tile = box row zr = TPW*wave + mt; lane (pair p, tap g): parity g & 1, entry p + (g >> 1)
-  int T[G::TPW];
-#pragma unroll
-  for (int mt = 0; mt < G::TPW; ++mt) {
-    const int zr = G::TPW * wave + mt;
-    const int r0 = ((zr / (2 * BZ2)) * G::H1 + (zr / BZ2) % 2) * G::H2 + zr % BZ2;
-    const int x3 = (2 * (lane & 15) + g - 1) & 31;       // tap g of the site pair (2p, 2p+1): sites 2p-1 .. 2p+2, wrapped
-    T[mt] = (x3 & 1) * G::SUB + r0 * G::ROWB + (x3 >> 1) * 16;
-  }
-  // ---- staging: wave w copies halo rows RPW*w .. RPW*w + RPW - 1, two per pass, one interior site per lane
-  const int rs = lane >> 5, xs = lane & 31;
-  auto row_offset = [&](const int (&o)[4], int row) {
-    const int z0 = row / (G::H1 * G::H2), z1 = (row / G::H2) % G::H1, z2 = row % G::H2;
-    int x0 = o[0] + z0 - 1, x1 = o[1] + z1 - 1, x2 = o[2] + z2 - 1;
-    x0 = x0 < 0 ? x0 + A.L[0] : (x0 >= A.L[0] ? x0 - A.L[0] : x0);
-    x1 = x1 < 0 ? x1 + A.L[1] : (x1 >= A.L[1] ? x1 - A.L[1] : x1);
-    x2 = x2 < 0 ? x2 + A.L[2] : (x2 >= A.L[2] ? x2 - A.L[2] : x2);
-    return ((x0 * A.L[1] + x1) * A.L[2] + x2) * A.L[3];
-  };
-  f16x8 qh[G::NPASS], ql[G::NPASS];
-  auto issue_item = [&](int b, const int (&o)[4]) {
-    const unsigned char *__restrict__ src = static_cast<const unsigned char *>(A.in) + int64_t(b) * A.V * 32;
-    const int myoff = row_offset(o, G::RPW * wave + (lane < G::RPW ? lane : 0));     // lane l: this wave's l-th halo row
-#pragma unroll
-    for (int i = 0; i < G::NPASS; ++i) {
-      const unsigned oa = unsigned(__builtin_amdgcn_readlane(myoff, 2 * i));
-      const unsigned ob = unsigned(__builtin_amdgcn_readlane(myoff, 2 * i + 1));
-      const unsigned voff = ((rs ? ob : oa) + unsigned(xs)) * 32u;       // uniform base + 32-bit lane offset (V*32 < 2^32)
-      qh[i] = *reinterpret_cast<const f16x8 *>(src + voff);
-      ql[i] = *reinterpret_cast<const f16x8 *>(src + voff + 16u);
-    }
-  };
-  // lane-constant part of the LDS address (row = RPW*wave + 2i + rs); per pass an immediate row offset is added
-  const int rbase = G::RPW * wave + rs;
-  const int d_main = (xs & 1) * G::SUB + rbase * G::ROWB + (xs >> 1) * 16;
-  auto commit_item = [&]() {
-#pragma unroll
-    for (int i = 0; i < G::NPASS; ++i) {
-      unsigned char *p0 = imgH + d_main + i * (2 * G::ROWB);
-      *reinterpret_cast<f16x8 *>(p0) = qh[i];
-      *reinterpret_cast<f16x8 *>(p0 + G::IMG) = ql[i];
-    }
-  };
-
-  // one site of an item's output: 8 channels (position t of the transpose) -> fp16 (hi, lo) -> 32 bytes
-  constexpr int NOUT = G::SITES / 256;                      // sites per thread
-  auto store_site = [&](const float (&v)[8], int b, const int (&o)[4], int t) {
-    const int zr = t >> 5, tp = t & 31;
-    const int x3 = 8 * ((tp >> 1) & 3) + 2 * (tp >> 3) + (tp & 1);          // the transpose's bank-conflict-free site order
-    f16x8 hi, lo;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const _Float16 hh = static_cast<_Float16>(v[c]);
-      hi[c] = hh;
-      lo[c] = static_cast<_Float16>(v[c] - static_cast<float>(hh));
-    }
-    const int x0 = o[0] + zr / (2 * BZ2), x1 = o[1] + (zr / BZ2) % 2, x2 = o[2] + zr % BZ2;
-    unsigned char *d = static_cast<unsigned char *>(A.out) +
-                       (int64_t(b) * A.V + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + x3) * 32;
-    *reinterpret_cast<f16x8 *>(d) = hi;
-    *reinterpret_cast<f16x8 *>(d + 16) = lo;
-  };
-  int pcb = 0, pco4[4] = {0, 0, 0, 0};                      // the previous item: its output is stored during this item's multiplications
-  int cb, co4[4], n1b, n1o[4];
-  decode(vb, cb, co4);
-  issue_item(cb, co4);
-  commit_item();
-  n1b = cb;
-#pragma unroll
-  for (int mu = 0; mu < 4; ++mu) n1o[mu] = co4[mu];
-  if (n_my > 1) {
-    advance(n1b, n1o);
-    issue_item(n1b, n1o);
-  }
-  lds_barrier();
-#ifdef NF_G_TIMING      // diagnostic build: cycle counters around the phases of an item (tools/g_bench.py prints them)
-  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
-#define NF_GTICK(k) { const unsigned long long tn = __builtin_readcyclecounter(); tacc[k] += tn - tprev; tprev = tn; }
-#else
-#define NF_GTICK(k)
-#endif
-  for (int m = 0; m < n_my; ++m) {
-    f32x4 acc[G::TPW];
-#pragma unroll
-    for (int mt = 0; mt < G::TPW; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // 27 slices (one per kernel row (j0, j1, j2)).  The wave's TPW site tiles are consecutive along axis 2 at one
-    // (z0, z1), so for a given (j0, j1) tile mt with tap j2 reads halo row mt + j2 of the same line: TPW + 2 row fragments
-    // serve 3 TPW (tile, j2) pairs -- each fragment is read from LDS once per (j0, j1), not once per use (halves the
-    // phase's LDS reads; it is bound by the matrix pipe after that).  Fragments of the next (j0, j1) are read one step
-    // (9 TPW MFMAs) ahead.
-    constexpr int NR = G::TPW + 2;
-    f16x8 fA[NR][2], fB[NR][2];                                   // [row][hi|lo]
-    auto fetch = [&](f16x8 (&a)[NR][2], int jj) {
-      const int off = ((jj / 3) * G::H1 + jj % 3) * G::H2 * G::ROWB;
-#pragma unroll
-      for (int q = 0; q < NR; ++q) {
-        a[q][0] = *reinterpret_cast<const f16x8 *>(imgH + T[0] + off + q * G::ROWB);
-        a[q][1] = *reinterpret_cast<const f16x8 *>(imgL + T[0] + off + q * G::ROWB);
-      }
-    };
-    auto mult = [&](const f16x8 (&a)[NR][2], int jj) {
-#pragma unroll
-      for (int j2 = 0; j2 < 3; ++j2)
-#pragma unroll
-        for (int mt = 0; mt < G::TPW; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt + j2][0], bh[3 * jj + j2], acc[mt], 0, 0, 0);
-#pragma unroll
-      for (int j2 = 0; j2 < 3; ++j2)
-#pragma unroll
-        for (int mt = 0; mt < G::TPW; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt + j2][0], bl[3 * jj + j2], acc[mt], 0, 0, 0);
-#pragma unroll
-      for (int j2 = 0; j2 < 3; ++j2)
-#pragma unroll
-        for (int mt = 0; mt < G::TPW; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt + j2][1], bh[3 * jj + j2], acc[mt], 0, 0, 0);
-    };
-    // the output of item m-1 leaves while item m multiplies: its transpose (the other ot buffer) is read before a step's
-    // MFMAs, converted and stored after them
-    const float *otp = ot + ((m + 1) & 1) * (8 * G::CS);
-    const bool outp = m > 0 && !NF_DBG(A, 4);
-    float ov[8];
-    auto out_load = [&](int k) {
-      if (outp) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) ov[c] = otp[c * G::CS + threadIdx.x + 256 * k];
-      }
-    };
-    auto out_store = [&](int k) {
-      if (outp) store_site(ov, pcb, pco4, threadIdx.x + 256 * k);
-    };
-    if (!NF_DBG(A, 1)) {
-      fetch(fA, 0);
-#pragma unroll
-      for (int jj = 0; jj < 9; jj += 2) {
-        if (jj + 1 < 9) fetch(fB, jj + 1);
-        if (jj / 2 < NOUT) out_load(jj / 2);
-        __builtin_amdgcn_sched_barrier(0);
-        mult(fA, jj);
-        __builtin_amdgcn_sched_barrier(0);
-        if (jj + 1 < 9) {
-          if (jj + 2 < 9) fetch(fA, jj + 2);
-          __builtin_amdgcn_sched_barrier(0);
-          mult(fB, jj + 1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (jj / 2 < NOUT) out_store(jj / 2);
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < NOUT; ++k) { out_load(k); out_store(k); }
-    }
-    NF_GTICK(0)     // MFMA steps (+ the previous item's output)
-    // bias + activation -> ot[co][box row][x3]: rows of D = pairs 4g + r of the tile
-    if (A.act == kActTanh) {          // one straight-line copy for the common activation (code size: see conv_c1_kernel)
-#pragma unroll
-      for (int mt = 0; mt < G::TPW; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[mt][r] = fast_tanh(acc[mt][r] * kInvWScale + bv);
-    } else {
-#pragma unroll
-      for (int mt = 0; mt < G::TPW; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[mt][r] = activate(acc[mt][r] * kInvWScale + bv, kActSigmoid);
-    }
-    {
-      // site 8g + 2r + shift of the tile's lattice row sits at position 8r + 2g + shift: with the channel stride CS = 8 mod 64
-      // the 64 lanes of a store (8 channels x 4 k-groups x 2 sites) then fall on 64 different banks
-      float *o0 = ot + (m & 1) * (8 * G::CS) + co * G::CS + (G::TPW * wave) * 32 + 2 * g + shift;
-#pragma unroll
-      for (int mt = 0; mt < G::TPW; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o0[mt * 32 + 8 * r] = acc[mt][r];
-    }
-    NF_GTICK(1)     // tanh + transpose stores
-    lds_barrier();                  // B0: the image is consumed, this item's ot is complete
-    NF_GTICK(2)     // barrier
-    // next item's image (loads issued one iteration ago), the loads of the item after next
-    if (m + 1 < n_my && !NF_DBG(A, 2)) commit_item();
-    NF_GTICK(3)     // commit
-    int n2b = n1b, n2o[4] = {n1o[0], n1o[1], n1o[2], n1o[3]};
-    if (m + 2 < n_my) {
-      advance(n2b, n2o);
-      if (!NF_DBG(A, 2)) issue_item(n2b, n2o);
-    }
-    NF_GTICK(4)     // issue: 96 KB per item through the CU's 64 B/clk load path -- 1.5 k cycles at best; moved behind the MFMA
-                    // steps the same cycles show up there (the waves issue in order)
-    lds_barrier();                  // B1: the next image is complete
-    NF_GTICK(5)     // barrier
-    pcb = cb;
-    cb = n1b;
-    n1b = n2b;
-#pragma unroll
-    for (int mu = 0; mu < 4; ++mu) { pco4[mu] = co4[mu]; co4[mu] = n1o[mu]; n1o[mu] = n2o[mu]; }
-  }
-#ifdef NF_G_TIMING
-  if (blockIdx.x == 8 && threadIdx.x == 0 && n_my > 100)
-    printf("[g timing] items %d | cycles per item: mfma %.0f  epilogue %.0f  barrier %.0f  commit %.0f  issue %.0f  barrier %.0f\n", n_my,
-           double(tacc[0]) / n_my, double(tacc[1]) / n_my, double(tacc[2]) / n_my, double(tacc[3]) / n_my, double(tacc[4]) / n_my, double(tacc[5]) / n_my);
-#endif
-  // the last item's output
-  if (!NF_DBG(A, 4)) {
-    const float *otp = ot + ((n_my - 1) & 1) * (8 * G::CS);
-#pragma unroll
-    for (int k = 0; k < NOUT; ++k) {
-      float ov[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) ov[c] = otp[c * G::CS + threadIdx.x + 256 * k];
-      store_site(ov, pcb, pco4, threadIdx.x + 256 * k);
-    }
-  }
-}
-
 }  // namespace nf
-
-using namespace nf;
-
-extern "C" int nf_conv_split16_supported(const int32_t *lattice, const int32_t *ksize, int cin, int cout, int act) {
-  using namespace nf::h;
-  if (!nf::option(NF_OPT_SPLIT16) || !lattice || !ksize || cin != 8 || cout != 8) return 0;
-  if (act != kActTanh && act != kActSigmoid) return 0;                    // the OUTPUT must be fp16-safe as well
-  for (int mu = 0; mu < 4; ++mu)
-    if (ksize[mu] != 3) return 0;
-  if (lattice[3] != 32) return 0;
-  for (int mu = 0; mu < 3; ++mu)
-    if (lattice[mu] < 2 || (lattice[mu] & 1)) return 0;
-  return 1;
-}
-
-extern "C" int nf_conv_fwd_split16(const void *in16, const void *wsplit, const void *bias, void *out16, int64_t B,
-                                   const int32_t *lattice, int act, void *stream_) {
-  using namespace nf::h;
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  NF_REQUIRE(in16 && wsplit && out16 && lattice, "nf_conv_fwd_split16: NULL pointer");
-  const int32_t k3[4] = {3, 3, 3, 3};
-  NF_REQUIRE(nf_conv_split16_supported(lattice, k3, 8, 8, act), "nf_conv_fwd_split16: layer not supported (needs a 32-site fastest axis, even other extents, tanh / sigmoid)");
-  NF_REQUIRE(B >= 0 && B <= 65535, "nf_conv_fwd_split16: batch outside [0, 65535]");
-  if (B == 0) return NF_OK;
-  ConvArgs A{};
-  A.in = in16; A.wfrag = wsplit; A.bias = bias; A.out = out16;
-  A.V = 1;
-  static const int bz2_env = NF_DIAG_ENV_INT("NF_CONVG_BZ2", 0);        // A/B knob
-  const int bz2 = bz2_env == 2 ? 2 : ((lattice[2] % 4 == 0) ? 4 : 2);
-  const int box[4] = {2, 2, bz2, 32};
-  int64_t nboxes = 1;
-  for (int mu = 0; mu < 4; ++mu) {
-    A.L[mu] = lattice[mu]; A.k[mu] = 3; A.box[mu] = box[mu];
-    A.nbox[mu] = lattice[mu] / box[mu];
-    A.V *= lattice[mu];
-    nboxes *= A.nbox[mu];
-  }
-  A.cin = 8; A.cout = 8; A.act = act;
-  {
-    static const int dbg = NF_DIAG_ENV_INT("NF_CONVG_DBG", 0);     // timing ablations: 1 no MFMA loop, 2 no staging, 4 no output
-    A.dbg = dbg;
-  }
-  A.nitems = B * nboxes;
-  A.nboxes = int(nboxes);
-  NF_REQUIRE(A.nitems < (int64_t(1) << 31) - 4096, "nf_conv_fwd_split16: batch x boxes >= 2^31 work items, split the batch");
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    hipDeviceProp_t prop;
-    NF_REQUIRE(hipGetDeviceProperties(&prop, dev) == hipSuccess, "nf_conv_fwd_split16: no device properties");
-    ncu = prop.multiProcessorCount;
-  }
-  int64_t grid = ncu;
-  if (grid > A.nitems) grid = A.nitems;
-  grid = (grid + 7) & ~int64_t(7);
-  if (bz2 == 4) {
-    NF_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_g_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, GeoG<4>::LDS) == hipSuccess,
-               "nf_conv_fwd_split16: cannot reserve %d B of LDS", GeoG<4>::LDS);
-    hipLaunchKernelGGL(conv_g_kernel<4>, dim3(unsigned(grid)), dim3(256), GeoG<4>::LDS, stream, A);
-  } else {
-    NF_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_g_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, GeoG<2>::LDS) == hipSuccess,
-               "nf_conv_fwd_split16: cannot reserve %d B of LDS", GeoG<2>::LDS);
-    hipLaunchKernelGGL(conv_g_kernel<2>, dim3(unsigned(grid)), dim3(256), GeoG<2>::LDS, stream, A);
-  }
-  return check_launch("conv split-fp16 two-site kernel");
-}

@@ -679,9 +679,9 @@ __global__ __launch_bounds__(kBlock, 2) void conv_c1_kernel(ConvArgs A) {
     const int x0 = o[0] + zr, x1 = o[1] + z1, x2 = o[2] + z2;
     if (x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2] && x3 < A.L[3]) {
       unsigned char *d = static_cast<unsigned char *>(A.out) + int64_t(b) * A.V * 32 +
-                         (((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + x3) * 32;
+                         ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * (A.L[3] * 32) + pair_row_offset(x3, A.L[3]);
       *reinterpret_cast<h8 *>(d) = hi;
-      *reinterpret_cast<h8 *>(d + 16) = lo;
+      *reinterpret_cast<h8 *>(d + A.L[3] * 16) = lo;
     }
   };
 #ifdef NF_C1_TIMING

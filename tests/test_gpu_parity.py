@@ -1118,11 +1118,10 @@ def test_split_fp16_hidden_layer_and_chain(shape, B):
     w = 0.2 * torch.randn((8, 8, 3, 3, 3, 3), generator=g, dtype=torch.float64, device='cpu')
     b = 0.3 * torch.randn(8, generator=g, dtype=torch.float64, device='cpu')
     ref = torch.tanh(O.circular_conv_fast(h, w, b))
-    hp = h.reshape(B, 8, V).permute(0, 2, 1).to(DEV, torch.float32).contiguous()
-    hi = hp.half()
-    h16 = torch.cat((hi, (hp - hi.float()).half()), dim=2).contiguous()
+    h16 = _hip.to_split16(h.to(DEV, torch.float32))
+    assert rel(_hip.from_split16(h16, shape), h) <= 1e-6            # the pair layout's own round trip
     out16 = _hip.conv_layer_split16(h16, w.to(DEV, torch.float32), b.to(DEV, torch.float32), _hip.ACT_CODES['tanh'], shape)
-    out = (out16[..., :8].float() + out16[..., 8:].float()).permute(0, 2, 1).reshape((B, 8) + shape)
+    out = _hip.from_split16(out16, shape)
     assert rel(out, ref) <= 1e-5        # (the fp32 kernels' bound for K = 648 terms is 1e-6 + 2e-7*0.3*648 = 4e-5)
     # the chain through the package API
     net = ConvAct(1, 46, 3, conv_dim=4, hidden_sizes=[8, 8], acts=['tanh', 'tanh', None]).to(DEV, torch.float32)

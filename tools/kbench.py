@@ -12,11 +12,19 @@ ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--lattice", type=str, default="32,32,32,32")
 ap.add_argument("--tag", type=str, default="")
+ap.add_argument("--only", type=str, default="")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 lattice = tuple(int(s) for s in a.lattice.split(","))
 net_, cpl = bench.build_net(lattice, 2, 16, dev, seed=2024)
+if a.only in ("g", "c"):
+    oth = bench.time_hidden_layers(cpl, lattice, dev, a.reps, a.batch)
+    print(f"[kbench {a.tag}] K5g {oth[1]['launch_ms']:.3f} ms  K5c {oth[0]['launch_ms']:.3f} ms", flush=True)
+    sys.exit(0)
 ft = bench.time_fused_last_layer(cpl, lattice, 16, dev, a.reps, a.batch)
+if a.only == "h":
+    print(f"[kbench {a.tag}] K5h {1e3*ft['seconds']:.3f} ms", flush=True)
+    sys.exit(0)
 oth = bench.time_hidden_layers(cpl, lattice, dev, a.reps, a.batch)
 print(f"[kbench {a.tag}] slab {ft['slab']}  K5h {1e3*ft['seconds']:.3f} ms  K5g {oth[1]['launch_ms']:.3f} ms  K5c {oth[0]['launch_ms']:.3f} ms  "
       f"sum {1e3*ft['seconds'] + oth[1]['launch_ms'] + oth[0]['launch_ms']:.3f} ms", flush=True)
