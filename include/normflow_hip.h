@@ -244,6 +244,18 @@ int nf_conv_weight_layout(const int32_t *lattice, const int32_t *ksize, int cin,
  *   and split as in NF_WLAYOUT_SPLIT16; bias (8) fp32 or NULL; act must keep |out| <= 1 (tanh, logistic).
  *   nf_conv_split16_supported: 3^4 kernel, 8 -> 8 channels, 32-site fastest axis, even other extents. */
 int nf_conv_split16_supported(const int32_t *lattice, const int32_t *ksize, int cin, int cout, int act);
+/* The FIRST ConvAct layer (1 -> 8 channels, 3^4 kernel, tanh / logistic) in front of the two entry points above (nf_conv_c.hip):
+ * fp32 field in, fp16 pair tensor out, every fp32 product as three fp16 matrix-core products (x = x_hi + x_lo, |x| below the
+ * fp16 range: beyond 6.5e4 the outputs are NaN, never silently wrong).
+ *   in (B, V) fp32 (the frozen half of the field, one channel); out16 (B, V, 16) halfs; bias (8) fp32 or NULL;
+ *   wsplit: [K slice (4)][hi|lo][64 lanes][8] halfs: K index = 4 r + t, r = kernel row (j0, j1, j2) row-major (27, padded to
+ *   32 with zeros), t = tap of the site pair (sites 2p-1 .. 2p+2); lane 16*g + n (column n = 8*shift + co) holds rows
+ *   8*slice + 2*g + h (h = 0, 1) as values 4*h + t = W[co][r][t - shift] (zero outside 0..2), scaled by 2^10 and split as
+ *   in NF_WLAYOUT_SPLIT16.  nf_conv_first_split16_supported: 8 output channels, 3^4 kernel, 32-site fastest axis, even
+ *   other extents. */
+int nf_conv_first_split16_supported(const int32_t *lattice, const int32_t *ksize, int cout, int act);
+int nf_conv_first_split16(const void *in, const void *wsplit, const void *bias, void *out16, int64_t B,
+                          const int32_t *lattice, int act, void *stream);
 int nf_conv_fwd_split16(const void *in16, const void *wsplit, const void *bias, void *out16, int64_t B,
                         const int32_t *lattice, int act, void *stream);
 /* Which kernel the calling thread's last nf_conv_fwd / nf_conv_rqs launched: 0 = one box per workgroup

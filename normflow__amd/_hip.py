@@ -71,6 +71,8 @@ PROTOTYPES = {
     "nf_conv_last_path": (_I, []),
     "nf_conv_split16_supported": (_I, [_P, _P, _I, _I, _I]),
     "nf_conv_fwd_split16": (_I, [_P, _P, _P, _P, _I64, _P, _I, _P]),
+    "nf_conv_first_split16_supported": (_I, [_P, _P, _I, _I]),
+    "nf_conv_first_split16": (_I, [_P, _P, _P, _P, _I64, _P, _I, _P]),
     "nf_conv_weight_layout": (_I, [_P, _P, _I, _I, _I, _I, _I]),
     "nf_conv_rqs": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I,
                          C.POINTER(RqsOpts), _I, _I, _P, _SZ, _I, _P]),
@@ -505,6 +507,47 @@ def pack_conv_weight_split16_two_site(w):
     return out.contiguous()
 
 
+def pack_conv_weight_split16_first(w):
+    """(8, 1, 3, 3, 3, 3) fp32 weights of a first ConvAct layer -> the B fragments of conv_c2_kernel (include/normflow_hip.h,
+    nf_conv_first_split16): [K slice (4)][hi|lo][lane (64)][8]; K index = 4 r + t with r the kernel row (j0, j1, j2) row-major
+    (27, zero-padded to 32) and t the tap of the site pair; lane 16*g + n (column n = 8*shift + co) holds rows 8*slice + 2*g + h
+    (h = 0, 1), taps t = 0..3, as value 4*h + t = W[co][r][t - shift] (zero outside 0..2), scaled by 2^10 and split."""
+    assert tuple(w.shape) == (8, 1, 3, 3, 3, 3)
+    wr = w.reshape(8, 27, 3).float() * SPLIT16_WEIGHT_SCALE              # co, row, j3
+    w2 = wr.new_zeros(16, 32, 4)                                         # column, row (padded), tap
+    w2[:8, :27, :3] = wr
+    w2[8:, :27, 1:] = wr
+    hi = w2.half()
+    lo = (w2 - hi.float()).half()
+    out = torch.empty(4, 2, 64, 8, dtype=torch.float16, device=w.device)
+    for k, part in enumerate((hi, lo)):
+        # part[n, r = 8 sl + 2 g + h, t] -> [sl, g, n, h, t]
+        v = part.reshape(16, 4, 4, 2, 4).permute(1, 2, 0, 3, 4)          # sl, g, n, h, t
+        out[:, k] = v.reshape(4, 64, 8)
+    return out.contiguous()
+
+
+def conv_first_split16(x, weight, bias, act):
+    """First ConvAct layer 1 -> 8 on the split-fp16 kernel (nf_conv_first_split16): x (B, 1, *L) fp32 -> the fp16 pair
+    tensor (B, V, 16); inference only."""
+    lib = load()
+    B = x.shape[0]
+    lat = list(x.shape[2:])
+    lat4 = (C.c_int32 * 4)(*lat)
+    V = 1
+    for n in lat:
+        V *= n
+    wsp = pack_conv_weight_split16_first(weight.detach())
+    bias = None if bias is None else bias.detach().float().contiguous()
+    out = torch.empty((B, V, 16), dtype=torch.float16, device=x.device)
+    step = max(1, min(MAX_B, ((1 << 31) - 1) // V))
+    for b0 in range(0, B, step):
+        b1 = min(B, b0 + step)
+        _check(lib.nf_conv_first_split16(_ptr(x[b0:b1]), _ptr(wsp), _ptr(bias), _ptr(out[b0:b1]), b1 - b0, lat4,
+                                         int(act), _stream()), "nf_conv_first_split16")
+    return out
+
+
 def _split16_site_index(L3, device):
     """idx[par, slot] = the site x3 of a lattice row stored in slot `slot` of parity block `par` of the fp16 pair layout
     (include/normflow_hip.h, NF_OUT_SPLIT16): even sites in order, odd sites rotated by one slot (slot s holds site 2s-1)."""
@@ -599,7 +642,10 @@ def _conv_launch(x, weight, bias, act, compact, parity):
     d = len(lat)
     lat4 = (C.c_int32 * 4)(*([1] * (4 - d) + lat))
     k4 = (C.c_int32 * 4)(*([1] * (4 - d) + ksize))
-    split16 = compact == 2                 # NF_OUT_SPLIT16: (B, V, 16) halfs, hi | lo per site
+    split16 = compact == 2                 # NF_OUT_SPLIT16: the fp16 (hi, lo) pair tensor, (B, V, 16) halfs
+    if (split16 and cin == 1 and cout == 8 and d == 4 and x.dtype == torch.float32 and _weights_fit_fp16(weight)
+            and lib.nf_conv_first_split16_supported(lat4, k4, cout, act)):
+        return conv_first_split16(x, weight, bias, act)
     if split16 and not (lib.nf_conv_two_site(cout, 0, lat[-1], ksize[-1]) and cout == 8 and x.dtype == torch.float32):
         raise NormflowHipError("split-fp16 output needs an fp32 two-site layer with 8 output channels")
     if lib.nf_conv_two_site(cout, 0 if split16 else int(compact), lat[-1], ksize[-1]):

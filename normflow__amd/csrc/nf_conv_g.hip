@@ -17,8 +17,8 @@
 //   * TWO WAVES PER SIMD, K SPLIT BETWEEN THEM.  The freed registers let 8 waves fit (<= 256 VGPRs each).  Waves w ("A") and
 //     w+4 ("B") share a SIMD and the two output tiles of position (z0, z1) of the cross-section; A multiplies slices 0..13,
 //     B slices 14..26, for BOTH tiles.  The partial sums cross through a 2 KiB LDS exchange (A gets tile 0's, B tile 1's),
-//     double-buffered, and each wave runs the epilogue of ITS tile of step s (add, bias, activation, transpose, split into
-//     (hi, lo), store) at the start of step s+1 -- beside its partner's MFMAs.  While one wave of a SIMD waits or does vector
+//     double-buffered, and each wave runs the epilogue of ITS tile of step s (add, bias, activation, split into (hi, lo),
+//     store -- straight from the accumulators: the weights are the MFMA's A operand, so a lane holds 4 channels of one site) at the start of step s+1 -- beside its partner's MFMAs.  While one wave of a SIMD waits or does vector
 //     work, the other's MFMAs keep the matrix pipe busy; the one-wave-per-SIMD form spent 42 % of an item outside its MFMAs.
 //   * ONE barrier per step; scalar bookkeeping per step is a handful of instructions (addresses are advanced, not recomputed:
 //     with 64-bit multiplications per DMA piece the pieces cost ~450 cycles each and the waves were scalar-bound).
@@ -44,13 +44,10 @@ constexpr int PLANE = PLROWS * RB;            // 16 KiB
 constexpr int NSLOT = 8;                      // ring: 4 planes being read + 4 ahead
 constexpr int RING = NSLOT * PLANE;           // 128 KiB
 constexpr int XBUF = 4 * 2 * 64 * 16;         // partial-sum exchange: [wave pair][direction][lane] x 16 B, one of two buffers
-constexpr int OTS = 48;                       // bytes per site in a wave's private transpose (32 B of data; 48 keeps the 16
-                                              // lanes of a ds_read_b128 group on different banks)
-constexpr int OTW = 32 * OTS;                 // one wave: one tile of 32 sites
-constexpr int LDS_BYTES = RING + 2 * XBUF + 8 * OTW;        // 131072 + 16384 + 12288 = 159744 <= 163840
+constexpr int LDS_BYTES = RING + 2 * XBUF;                  // 131072 + 16384 = 147456 <= 163840
 constexpr int NSA = 14;                       // slices of the A waves (0..13); B waves: 14..26
 constexpr float kInvWScale = 1.0f / 1024.0f;  // the weights are packed scaled by 2^10 (normflow__amd/_hip.py: SPLIT16_WEIGHT_SCALE)
-static_assert(LDS_BYTES <= 160 * 1024, "ring + exchange + transposes must fit the CU's LDS");
+static_assert(LDS_BYTES <= 160 * 1024, "ring + exchange must fit the CU's LDS");
 }  // namespace g2
 
 // One LDS-DMA piece: 64 lanes x 16 bytes from sbase + voff (per lane) to the 1 KiB at LDS byte address `lds` (wave-uniform).
@@ -117,9 +114,13 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
       bl[r] = wsp[(2 * rc + 1) * 64];
     }
   }
-  const int col = lane & 15, co = col & 7, shift = col >> 3;
-  const float bv = A.bias ? static_cast<const float *>(A.bias)[co] : 0.f;
-  const float kc1 = 2.885390081777927f * kInvWScale, kc0 = 2.885390081777927f * bv;      // 2 log2(e) x (scale, bias)
+  float bv4[4], kc0[4];                        // bias of the four channels this lane ends up with: 4 (g & 1) + r
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    bv4[r] = A.bias ? static_cast<const float *>(A.bias)[4 * (g & 1) + r] : 0.f;
+    kc0[r] = 2.885390081777927f * bv4[r];      // 2 log2(e) x bias
+  }
+  const float kc1 = 2.885390081777927f * kInvWScale;
 
   // ---- A-fragment addressing.  Lane (pair p, k-group g) reads tap g of its pair: site 2p + g - 1 (mod L3) -- parity block
   // (g + 1) & 1, slot p + (g >> 1) (mod 16) of the row image (pair_row_offset).  The row of tile t (plane 2s + t of the step) at
@@ -189,13 +190,11 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
   bool have_prev = false;
   int free_next = 0;                          // ring entries freed by the previous step (2, or 4 at a column end)
   const int nsteps_total = ncols_my * nstep;
-  unsigned char *otw = smem_g2 + RING + 2 * XBUF + wave * OTW;              // this wave's private transpose
   // exchange slots of this pair in a buffer: [0] A -> B (tile 1's partial sums of A), [1] B -> A (tile 0's of B)
   const unsigned xsend = unsigned(RING + (q * 2 + (isB ? 1 : 0)) * 1024 + lane * 16);
   const unsigned xrecv = unsigned(RING + (q * 2 + (isB ? 0 : 1)) * 1024 + lane * 16);
-  // the store pass of the epilogue: lane = (site sx, channel half hh)
-  const int sx = lane & 31, hh = lane >> 5;
-  const unsigned lane_o = unsigned(pair_row_offset(sx, L3) + hh * 8);
+  // the epilogue's store: lane (p, g) holds channels 4 (g & 1) .. + 3 of site 2p + (g >> 1)
+  const unsigned lane_o = unsigned(pair_row_offset(2 * p + (g >> 1), L3) + (g & 1) * 8);
 
 #if defined(NF_DIAG) && defined(NF_G2_TIMING)      // diagnostic build: cycle counters around the phases of a step
   unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
@@ -204,28 +203,16 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
 #define NF_G2TICK(i)
 #endif
   auto epilogue = [&](int xbuf) {
-    // partner's partial sums of my tile + mine -> bias, activation -> transpose -> (hi, lo) halves of 4 channels per lane
+    // partner's partial sums of my tile + mine -> bias, activation -> (hi, lo) halves of this lane's 4 channels of its site
     const f32x4 pa = *reinterpret_cast<const f32x4 *>(smem_g2 + xbuf * XBUF + xrecv);
-    float *ot = reinterpret_cast<float *>(otw);
-    float av[4];
-    if (A.act == kActTanh) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) av[r] = tanh_affine(prev[r] + pa[r], kc1, kc0);
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) av[r] = activate((prev[r] + pa[r]) * kInvWScale + bv, kActSigmoid);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)               // row 4g + r of the tile = pair 4g + r: site 2 (4g + r) + shift
-      ot[(8 * g + 2 * r + shift) * (OTS / 4) + co] = av[r];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // wave-local transpose: my own stores, in order
-    const f32x4 v = *reinterpret_cast<const f32x4 *>(otw + sx * OTS + hh * 16);
     f16x4 hi, lo;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const _Float16 h0 = static_cast<_Float16>(v[c]);
-      hi[c] = h0;
-      lo[c] = static_cast<_Float16>(v[c] - static_cast<float>(h0));
+    for (int r = 0; r < 4; ++r) {
+      const float a = prev[r] + pa[r];
+      const float v = A.act == kActTanh ? tanh_affine(a, kc1, kc0[r]) : activate(a * kInvWScale + bv4[r], kActSigmoid);
+      const _Float16 h0 = static_cast<_Float16>(v);
+      hi[r] = h0;
+      lo[r] = static_cast<_Float16>(v - static_cast<float>(h0));
     }
     unsigned char *d = pout + lane_o;
     *reinterpret_cast<f16x4 *>(d) = hi;
@@ -272,7 +259,9 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
         }
       }
     };
-    // taps J0 .. J1 of a combo whose tap 0 is my local slice `base` (compile-time at every call site)
+    // taps J0 .. J1 of a combo whose tap 0 is my local slice `base` (compile-time at every call site).  The WEIGHTS are the
+    // MFMA's A operand (rows m = column (shift, co) of the layer), the site pairs its B operand: D[m][pair] leaves the four
+    // channels 4 (g & 1) .. + 3 of ONE site (2p + (g >> 1)) in each lane -- what a store needs, no transpose
     auto mult = [&](const f16x8 (&fh)[4], const f16x8 (&fl)[4], int base, int J0, int J1) {
       if (NF_G2_ABL & 4) {
 #pragma unroll
@@ -283,17 +272,17 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
       for (int j2 = 0; j2 < 3; ++j2)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-          if (j2 >= J0 && j2 <= J1) am[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[t + j2], bh[base + j2], am[t], 0, 0, 0);
+          if (j2 >= J0 && j2 <= J1) am[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[base + j2], fh[t + j2], am[t], 0, 0, 0);
 #pragma unroll
       for (int j2 = 0; j2 < 3; ++j2)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-          if (j2 >= J0 && j2 <= J1) ac[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[t + j2], bl[base + j2], ac[t], 0, 0, 0);
+          if (j2 >= J0 && j2 <= J1) ac[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[base + j2], fh[t + j2], ac[t], 0, 0, 0);
 #pragma unroll
       for (int j2 = 0; j2 < 3; ++j2)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-          if (j2 >= J0 && j2 <= J1) ac[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[t + j2], bh[base + j2], ac[t], 0, 0, 0);
+          if (j2 >= J0 && j2 <= J1) ac[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[base + j2], fl[t + j2], ac[t], 0, 0, 0);
     };
     auto combo_off = [](int jj) { return ((jj / 3) * 4 + jj % 3) * RB; };      // halo row (j0, j1) relative to the pair's own
     f16x8 fh0[4], fl0[4], fh1[4], fl1[4];

@@ -557,9 +557,10 @@ def _network_properties(shape, B, kinds, m=16):
     assert rel(xb, x) <= 2e-4 and float(lb.abs().max()) <= 2e-5 * max(1.0, float(lj.abs().max())) * 50
     assert torch.equal(yp, y[perm]) and torch.equal(ljp, lj[perm])
     y2, lj2 = net_(x[:1].clone().requires_grad_(True))        # differentiable path: logits materialised, K2 kernel
-    # (the fused path may run split-fp16 products, the differentiable path runs fp32 ones: two roundings of the same
-    #  exact result, each within north_star's 1e-5 of the fp64 oracle -- see the per-kernel tests)
-    assert rel(y2, y[:1]) <= 5e-6 and rel(lj2, lj[:1]) <= 2e-6
+    # (the fused path runs split-fp16 products in all three conv layers, the differentiable path fp32 ones: two roundings of
+    #  the same exact result, each within north_star's 1e-5 of the fp64 oracle -- see the per-kernel tests -- so within 2e-5
+    #  of each other)
+    assert rel(y2, y[:1]) <= 2e-5 and rel(lj2, lj[:1]) <= 1e-5, (rel(y2, y[:1]), rel(lj2, lj[:1]))
 
 
 def test_config4_network_properties():
