@@ -42,9 +42,11 @@ extern "C" {
 
 #define NF_VERSION 200 /* 0.2.0 */
 
-/* NF_F16 (nf_rqs_fwd / nf_rqs_inv only, knots_len 4/8/16): x, params and y are IEEE half, the arithmetic is fp32 and
+/* NF_F16 (nf_rqs_fwd / nf_rqs_inv with knots_len 4/8/16, nf_affine_fwd / nf_affine_inv): x, params and y are IEEE half, the arithmetic is fp32 and
  * log0 / logj are fp32 ("fp16 params / fp32 log-det accumulate", BASELINE config 5). */
-enum nf_dtype { NF_F32 = 0, NF_F64 = 1, NF_F16 = 2 };
+/* NF_F16_FIELD (nf_affine_fwd / nf_affine_inv only): x and y are IEEE half, params stay fp32 (what a conv layer wrote),
+ * fp32 arithmetic and log-det. */
+enum nf_dtype { NF_F32 = 0, NF_F64 = 1, NF_F16 = 2, NF_F16_FIELD = 3 };
 enum nf_layout { NF_LAYOUT_FULL = 0, NF_LAYOUT_PAIR = 1 };
 enum nf_extrap { NF_EXTRAP_NONE = 0, NF_EXTRAP_LINEAR = 1, NF_EXTRAP_ANTI = 2 };
 enum nf_status {
@@ -280,7 +282,9 @@ int nf_conv_last_path(void);
  */
 /*   NF_CONV_SPLIT16_INPUT (with NF_CONV_UNIT_INPUT): `in` is not (B, 8, V) fp32 but what the previous layer wrote
  *   with nf_conv_fwd(compact = NF_OUT_SPLIT16): (B, V, 16) IEEE halfs = per site hi[8] | lo[8]. */
-enum { NF_CONV_UNIT_INPUT = 1, NF_CONV_SPLIT16_INPUT = 2 };
+/*   NF_CONV_FIELD_F16: x_active and y are IEEE half (fp16 field storage; the arithmetic stays fp32 and log0 / logj stay fp32:
+ *   BASELINE config 5, "fp16 params / fp32 log-det accumulate" -- in the fused path the "params" never exist in memory). */
+enum { NF_CONV_UNIT_INPUT = 1, NF_CONV_SPLIT16_INPUT = 2, NF_CONV_FIELD_F16 = 4 };
 int nf_conv_rqs_supported(int cout, int m);
 int nf_conv_rqs(const void *in, const void *wfrag, const void *bias, const void *x_active,
                 const void *log0, void *y, void *logj, int64_t B, const int32_t *lattice,

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnormflow_hip.so")
 
-NF_F32, NF_F64, NF_F16 = 0, 1, 2
+NF_F32, NF_F64, NF_F16, NF_F16_FIELD = 0, 1, 2, 3
 LAYOUT_FULL, LAYOUT_PAIR = 0, 1
 EXTRAP = {None: 0, 'none': 0, 'linear': 1, 'anti': 2, 'anti-periodic': 2}
 
@@ -168,13 +168,14 @@ def _ptr(t):
 
 def _log0_tensor(log0, like, B):
     """log0 may be the python number 0 (nn/_core.py:25 default) or a (B,) tensor."""
+    dt = torch.float32 if like.dtype == torch.float16 else like.dtype       # fp16 fields accumulate log|J| in fp32
     if torch.is_tensor(log0):
         if log0.dim() == 0:
             log0 = log0.expand(B)
-        return log0.to(dtype=like.dtype, device=like.device).contiguous()
+        return log0.to(dtype=dt, device=like.device).contiguous()
     if log0 == 0:
         return None
-    return torch.full((B,), float(log0), dtype=like.dtype, device=like.device)
+    return torch.full((B,), float(log0), dtype=dt, device=like.device)
 
 
 MAX_B = 32768  # the batch is the grid's y extent; larger batches are cut into slabs
@@ -331,19 +332,33 @@ class AffineCouplingFn(torch.autograd.Function):
         _require_device(v, params, mask, log0)
         B, V = v.shape
         v, params = v.contiguous(), params.contiguous()
-        if params.dtype != v.dtype:
-            raise TypeError(f"field is {v.dtype} but net output is {params.dtype}")
+        if v.dtype == torch.float16:
+            # fp16 field storage (BASELINE config 5): params either half as well (NF_F16) or the fp32 a conv layer wrote
+            # (NF_F16_FIELD); fp32 arithmetic, fp32 log-det
+            if params.dtype == torch.float16:
+                code = NF_F16
+            elif params.dtype == torch.float32:
+                code = NF_F16_FIELD
+            else:
+                raise TypeError(f"half field with {params.dtype} parameters")
+            ldt = torch.float32
+        else:
+            if params.dtype != v.dtype:
+                raise TypeError(f"field is {v.dtype} but net output is {params.dtype}")
+            code, ldt = _dtype_code(v), v.dtype
+        if log0 is not None and log0.dtype != ldt:
+            raise TypeError(f"log0 must be {ldt} for a {v.dtype} field")
         n_ch = params.shape[1]
         lib = load()
         out = torch.empty_like(v)
-        logj = torch.empty(B, dtype=v.dtype, device=v.device)
+        logj = torch.empty(B, dtype=ldt, device=v.device)
         ws = _workspace(min(B, MAX_B), V, v.device)
         fn = lib.nf_affine_inv if inverse else lib.nf_affine_fwd
         for b0 in range(0, B, MAX_B):
             b1 = min(B, b0 + MAX_B)
             l0 = log0[b0:b1] if log0 is not None else None
             _check(fn(_ptr(v[b0:b1]), _ptr(params[b0:b1]), _ptr(mask), _ptr(l0), _ptr(out[b0:b1]),
-                      _ptr(logj[b0:b1]), b1 - b0, V, n_ch, layout, _ptr(ws), ws.numel(), _dtype_code(v),
+                      _ptr(logj[b0:b1]), b1 - b0, V, n_ch, layout, _ptr(ws), ws.numel(), code,
                       _stream()), "nf_affine")
         ctx.save_for_backward(v, params, mask)
         ctx.layout, ctx.inverse, ctx.has_log0 = layout, inverse, log0 is not None
@@ -352,6 +367,8 @@ class AffineCouplingFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout, glogj):
         v, params, mask = ctx.saved_tensors
+        if v.dtype == torch.float16:
+            raise NotImplementedError("fp16 storage is an inference path (nf_affine_fwd / nf_affine_inv); train in fp32")
         B, V = v.shape
         gout, glogj = gout.contiguous(), glogj.contiguous()
         gin, gpar = torch.empty_like(v), torch.empty_like(params)
@@ -786,6 +803,10 @@ def conv_rqs(h, weight, bias, x_active, log0, parity, opts, inverse, unit_input=
     k4 = (C.c_int32 * 4)(*([1] * (4 - d) + list(weight.shape[2:])))
     V = x_active.shape[1]
     flags = 1 if (unit_input and _weights_fit_fp16(weight)) else 0          # NF_CONV_UNIT_INPUT: |h| <= 1 (tanh outputs)
+    field16 = x_active.dtype == torch.float16                                # NF_CONV_FIELD_F16: fp16 field storage
+    if field16:
+        flags |= 4
+    ldt = torch.float32 if field16 else x_active.dtype
     if split_in:
         if not flags or h.dtype != torch.float16 or tuple(h.shape) != (B, V, 16):
             raise NormflowHipError("split-fp16 hidden activations need unit_input and a (B, V, 16) half tensor")
@@ -794,12 +815,12 @@ def conv_rqs(h, weight, bias, x_active, log0, parity, opts, inverse, unit_input=
     bias = None if bias is None else bias.detach().contiguous()
     if out is None:
         y = torch.empty_like(x_active)
-        logj = torch.empty(B, dtype=x_active.dtype, device=x_active.device)
+        logj = torch.empty(B, dtype=ldt, device=x_active.device)
     else:
         y, logj = out
-        if (tuple(y.shape) != (B, V) or tuple(logj.shape) != (B,) or y.dtype != x_active.dtype or logj.dtype != x_active.dtype
+        if (tuple(y.shape) != (B, V) or tuple(logj.shape) != (B,) or y.dtype != x_active.dtype or logj.dtype != ldt
                 or not y.is_contiguous() or not logj.is_contiguous()):
-            raise NormflowHipError("conv_rqs: `out` must be contiguous (B, V) and (B,) tensors of the input's dtype")
+            raise NormflowHipError("conv_rqs: `out` must be contiguous (B, V) and (B,) tensors of the input's dtype (log|J| fp32 for a half field)")
         _require_device(y, logj)
     ws = _workspace(min(B, MAX_B), V, h.device)
     for b0 in range(0, B, MAX_B):

@@ -3,6 +3,7 @@
 //   fwd  y = t + x e^{-|s|},  logJ -= sum|s|      inv  x = (y - t) e^{|s|},  logJ += sum|s|
 // with t, s read only at active sites (the reference's two `purify` passes) and the
 // per-sample sum (src/nn/_core.py:38-42) done by wave shuffles + one double per workgroup.
+#include <hip/hip_fp16.h>
 #include "nf_internal.h"
 
 namespace nf {
@@ -25,14 +26,40 @@ template <typename T> struct Pair2a;
 template <> struct Pair2a<float> { typedef float2 type; };
 template <> struct Pair2a<double> { typedef double2 type; };
 
-template <typename T, bool INV, bool PAIR>
+// Storage adaptors: T = arithmetic type; SX = storage of the field (x, y), SP = storage of the parameters.  SX = SP = T for
+// fp32 / fp64; SX = __half (and SP = __half or float) for BASELINE config 5's fp16 storage with fp32 arithmetic and log-det.
+template <typename T, typename S> struct Store {
+  static __device__ __forceinline__ T ld(const S *p, int64_t i) { return T(p[i]); }
+  static __device__ __forceinline__ void ld2(const S *p, int64_t u, T &a, T &b) {
+    const typename Pair2a<T>::type v = reinterpret_cast<const typename Pair2a<T>::type *>(p)[u];
+    a = v.x; b = v.y;
+  }
+  static __device__ __forceinline__ void st(S *p, int64_t i, T v) { p[i] = S(v); }
+  static __device__ __forceinline__ void st2(S *p, int64_t u, T a, T b) {
+    typename Pair2a<T>::type o;
+    o.x = a; o.y = b;
+    reinterpret_cast<typename Pair2a<T>::type *>(p)[u] = o;
+  }
+};
+template <> struct Store<float, __half> {
+  static __device__ __forceinline__ float ld(const __half *p, int64_t i) { return __half2float(p[i]); }
+  static __device__ __forceinline__ void ld2(const __half *p, int64_t u, float &a, float &b) {
+    const float2 v = __half22float2(reinterpret_cast<const __half2 *>(p)[u]);
+    a = v.x; b = v.y;
+  }
+  static __device__ __forceinline__ void st(__half *p, int64_t i, float v) { p[i] = __float2half_rn(v); }
+  static __device__ __forceinline__ void st2(__half *p, int64_t u, float a, float b) {
+    reinterpret_cast<__half2 *>(p)[u] = __float22half2_rn(float2{a, b});
+  }
+};
+
+template <typename T, typename SX, typename SP, bool INV, bool PAIR>
 __global__ __launch_bounds__(kBlock) void affine_kernel(AffArgs A) {
   __shared__ double red[kBlock / kWave];
-  typedef typename Pair2a<T>::type P2;
   const int b = blockIdx.y;
-  const T *__restrict__ vin = static_cast<const T *>(A.v) + int64_t(b) * A.V;
-  const T *__restrict__ par = static_cast<const T *>(A.params) + int64_t(b) * A.n_ch * A.Vp;
-  T *__restrict__ out = static_cast<T *>(A.out) + int64_t(b) * A.V;
+  const SX *__restrict__ vin = static_cast<const SX *>(A.v) + int64_t(b) * A.V;
+  const SP *__restrict__ par = static_cast<const SP *>(A.params) + int64_t(b) * A.n_ch * A.Vp;
+  SX *__restrict__ out = static_cast<SX *>(A.out) + int64_t(b) * A.V;
   double acc = 0.0;
   const int64_t base = int64_t(blockIdx.x) * kBlock * A.iters + threadIdx.x;
   for (int it = 0; it < A.iters; ++it) {
@@ -43,26 +70,21 @@ __global__ __launch_bounds__(kBlock) void affine_kernel(AffArgs A) {
     int off = 0;
     if (PAIR) {
       off = (reinterpret_cast<const uint16_t *>(A.mask)[u] & 0xff) ? 0 : 1;
-      const P2 xv = reinterpret_cast<const P2 *>(vin)[u];
-      v = off ? xv.y : xv.x;
+      T xa, xb;
+      Store<T, SX>::ld2(vin, u, xa, xb);
+      v = off ? xb : xa;
     } else {
       active = A.mask[u] != 0;
-      v = vin[u];
+      v = Store<T, SX>::ld(vin, u);
     }
     if (active) {
-      const T t = par[u];
-      const T s = A.n_ch > 1 ? Num<T>::abs(par[A.Vp + u]) : T(0);
+      const T t = Store<T, SP>::ld(par, u);
+      const T s = A.n_ch > 1 ? Num<T>::abs(Store<T, SP>::ld(par, A.Vp + u)) : T(0);
       val = INV ? (v - t) * nf_exp(s) : t + v * nf_exp(-s);
       ls = INV ? s : -s;
     }
-    if (PAIR) {
-      P2 o;
-      o.x = off ? T(0) : val;
-      o.y = off ? val : T(0);
-      reinterpret_cast<P2 *>(out)[u] = o;
-    } else {
-      out[u] = val;
-    }
+    if (PAIR) Store<T, SX>::st2(out, u, off ? T(0) : val, off ? val : T(0));
+    else Store<T, SX>::st(out, u, val);
     acc += double(ls);
   }
   const double tot = block_sum(acc, red);
@@ -142,7 +164,7 @@ static int fill(AffArgs &A, int64_t B, int64_t V, int n_ch, int layout, const ui
   return NF_OK;
 }
 
-template <typename T, bool INV>
+template <typename T, bool INV, typename SX = T, typename SP = T>
 static int run_map(const void *v, const void *params, const uint8_t *mask, const void *log0, void *out,
                    void *logj, int64_t B, int64_t V, int n_ch, int layout, void *ws, size_t ws_bytes,
                    hipStream_t stream) {
@@ -160,8 +182,8 @@ static int run_map(const void *v, const void *params, const uint8_t *mask, const
   A.v = v; A.params = params; A.out = out; A.partial = static_cast<double *>(ws); A.iters = t.iters;
   if (t.blocks_x > 0) {
     const dim3 grid(unsigned(t.blocks_x), unsigned(B));
-    if (layout == NF_LAYOUT_PAIR) hipLaunchKernelGGL((affine_kernel<T, INV, true>), grid, dim3(kBlock), 0, stream, A);
-    else hipLaunchKernelGGL((affine_kernel<T, INV, false>), grid, dim3(kBlock), 0, stream, A);
+    if (layout == NF_LAYOUT_PAIR) hipLaunchKernelGGL((affine_kernel<T, SX, SP, INV, true>), grid, dim3(kBlock), 0, stream, A);
+    else hipLaunchKernelGGL((affine_kernel<T, SX, SP, INV, false>), grid, dim3(kBlock), 0, stream, A);
     rc = check_launch("affine kernel");
     if (rc) return rc;
   }
@@ -196,6 +218,8 @@ extern "C" int nf_affine_fwd(const void *x, const void *params, const uint8_t *m
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == NF_F32) return run_map<float, false>(x, params, mask, log0, y, logj, B, V, n_ch, layout, workspace, workspace_bytes, s);
   if (dtype == NF_F64) return run_map<double, false>(x, params, mask, log0, y, logj, B, V, n_ch, layout, workspace, workspace_bytes, s);
+  if (dtype == NF_F16) return run_map<float, false, __half, __half>(x, params, mask, log0, y, logj, B, V, n_ch, layout, workspace, workspace_bytes, s);
+  if (dtype == NF_F16_FIELD) return run_map<float, false, __half, float>(x, params, mask, log0, y, logj, B, V, n_ch, layout, workspace, workspace_bytes, s);
   set_error("nf_affine_fwd: unsupported dtype %d", dtype);
   return NF_EINVAL;
 }
@@ -206,6 +230,8 @@ extern "C" int nf_affine_inv(const void *y, const void *params, const uint8_t *m
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == NF_F32) return run_map<float, true>(y, params, mask, log0, x, logj, B, V, n_ch, layout, workspace, workspace_bytes, s);
   if (dtype == NF_F64) return run_map<double, true>(y, params, mask, log0, x, logj, B, V, n_ch, layout, workspace, workspace_bytes, s);
+  if (dtype == NF_F16) return run_map<float, true, __half, __half>(y, params, mask, log0, x, logj, B, V, n_ch, layout, workspace, workspace_bytes, s);
+  if (dtype == NF_F16_FIELD) return run_map<float, true, __half, float>(y, params, mask, log0, x, logj, B, V, n_ch, layout, workspace, workspace_bytes, s);
   set_error("nf_affine_inv: unsupported dtype %d", dtype);
   return NF_EINVAL;
 }

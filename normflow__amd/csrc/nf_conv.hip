@@ -606,6 +606,7 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
   if (fz) {
     fuse = fz->mode;
     A.xact = fz->xact; A.yout = fz->yout; A.partial = fz->partial; A.P = fz->P;
+    A.field16 = (fz->flags & NF_CONV_FIELD_F16) ? 1 : 0;
     NF_REQUIRE(A.nt_total <= 3, "nf_conv_rqs: at most 48 logit channels can be fused");
     const size_t need = size_t(B) * size_t(nblocks) * sizeof(double);
     if (fz->partial == nullptr || fz->partial_bytes < need) {

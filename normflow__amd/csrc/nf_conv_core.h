@@ -64,6 +64,7 @@ struct ConvArgs {
   int packed, ns;       // packed: K = (tap, ci) flattened, 4 per step, ns steps (multiple of 4)
   unsigned long long *stamps;   // diagnostic build only (NF_CONV_STAMPS): 8 clock stamps per workgroup
   int dbg;              // DIAGNOSTIC builds only (make DIAG=1; NF_CONV_DBG / NF_CONVG_DBG timing ablations that skip work): always 0 otherwise
+  int field16;          // fused coupling epilogue: xact / yout are IEEE half (NF_CONV_FIELD_F16: fp16 field storage, fp32 arithmetic)
   int in_split16;       // nf_conv_rqs: `in` is the (B, V, 16) fp16 (hi, lo) pair tensor a previous layer wrote (NF_CONV_SPLIT16_INPUT)
   int64_t nitems;       // nf_conv_pipe.hip: (sample, box) items in the launch, boxes per sample
   int nboxes;
@@ -81,6 +82,18 @@ __host__ __device__ __forceinline__ int pair_row_offset(int x3, int L3) {
   int slot = (x3 + par) >> 1;
   slot = slot >= (L3 >> 1) ? slot - (L3 >> 1) : slot;
   return par * (L3 * 8) + slot * 16;
+}
+
+// The field of a fused coupling epilogue: a pair (sites 2h, 2h+1) as fp32 or -- NF_CONV_FIELD_F16 -- IEEE half storage
+// (BASELINE config 5: fp16 fields / fp32 log-det; the arithmetic is fp32 either way).
+#include <hip/hip_fp16.h>
+__device__ __forceinline__ float2 load_field_pair(const ConvArgs &A, int64_t pair) {
+  if (A.field16) return __half22float2(reinterpret_cast<const __half2 *>(A.xact)[pair]);
+  return reinterpret_cast<const float2 *>(A.xact)[pair];
+}
+__device__ __forceinline__ void store_field_pair(const ConvArgs &A, int64_t pair, float2 v) {
+  if (A.field16) reinterpret_cast<__half2 *>(A.yout)[pair] = __float22half2_rn(v);
+  else reinterpret_cast<float2 *>(A.yout)[pair] = v;
 }
 
 // tanh on the hardware exp/rcp: (1 - t) / (1 + t), t = exp(-2|v|); absolute error ~1e-7 (the fp32 rounding of an
@@ -207,7 +220,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, const int (&o)[
       if (x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2] && x3p < A.L[3] / 2) {
         const int off = (A.parity + x0 + x1 + x2) & 1;  // which site of the pair is active
         const int64_t pair = int64_t(b) * (A.V / 2) + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * (A.L[3] / 2) + x3p;
-        const float2 xv = reinterpret_cast<const float2 *>(A.xact)[pair];
+        const float2 xv = load_field_pair(A, pair);
         RegCol<float, C> a;
 #pragma unroll
         for (int c = 0; c < C; ++c) a[c] = pt[c * PU + threadIdx.x];
@@ -216,7 +229,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, const int (&o)[
         float2 ov;
         ov.x = off ? 0.f : val;
         ov.y = off ? val : 0.f;
-        reinterpret_cast<float2 *>(A.yout)[pair] = ov;
+        store_field_pair(A, pair, ov);
         lacc = double(logd);
       }
     }

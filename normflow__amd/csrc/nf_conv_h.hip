@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   float2 xpre[2] = {{0.f, 0.f}, {0.f, 0.f}};     // the x pairs of the item whose logits are (about to be) in pt
   auto prefetch_x = [&](int b, const int (&o)[4]) {
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) xpre[pass] = reinterpret_cast<const float2 *>(A.xact)[pair_of(b, o, pass)];
+    for (int pass = 0; pass < 2; ++pass) xpre[pass] = load_field_pair(A, pair_of(b, o, pass));
   };
   auto epilogue = [&](int b, const int (&o)[4], int64_t pidx) {
     const lds_f *ptl = (const lds_f *)(smem_h + 4 * IMG);
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       float2 ov;
       ov.x = offp ? 0.f : val;
       ov.y = offp ? val : 0.f;
-      reinterpret_cast<float2 *>(A.yout)[pair] = ov;
+      store_field_pair(A, pair, ov);
       lacc += double(logd);
     }
     const double tot = wave_sum(lacc);

@@ -104,7 +104,10 @@ class Coupling_(Module_, ABC):
 
     def _params(self, net, x_frozen, parity=None):
         """Run the parameter net; return raw logits as (B, C, V) [or (B, C, V/2)] and the
-        layout code.  A ConvAct on a plain even-odd mask emits only the active sites."""
+        layout code.  A ConvAct on a plain even-odd mask emits only the active sites.
+        fp16 fields (BASELINE config 5): the net computes in fp32 on the widened frozen half."""
+        if x_frozen.dtype == torch.float16:
+            x_frozen = x_frozen.float()
         if (parity is not None and self.channels_axis == 1 and hasattr(net, 'forward_active')
                 and getattr(self.mask, 'pairable', False) and hasattr(self.mask, 'checkerboard_parity')):
             a = self.mask.checkerboard_parity(parity)
@@ -221,7 +224,7 @@ class RQSplineCoupling_(Coupling_):
             return None
         if (self.propagate_density or self.channels_axis != 1 or self.knots_x is not None
                 or self.knots_y is not None or not hasattr(net, 'hidden_and_last')
-                or not getattr(self.mask, 'pairable', False) or x_active.dtype != torch.float32
+                or not getattr(self.mask, 'pairable', False) or x_active.dtype not in (torch.float32, torch.float16)
                 or not hasattr(self.mask, 'checkerboard_parity')):
             return None
         a = self.mask.checkerboard_parity(parity)
@@ -234,9 +237,10 @@ class RQSplineCoupling_(Coupling_):
         hidden = max(net.conv_kwargs['hidden_sizes'] or [1])
         v = v.contiguous()
         val = torch.empty_like(v)               # the slabs write their rows in place: no concatenation
-        lj = torch.empty(B, dtype=v.dtype, device=v.device)
+        lj = torch.empty(B, dtype=torch.float32 if v.dtype == torch.float16 else v.dtype, device=v.device)
         for b0, b1 in self._slabs(B, hidden * v.shape[1] * 4, self.HIDDEN_SLAB_BYTES):
-            got = net.hidden_and_last(self.preprocess_fz(x_frozen[b0:b1]))
+            xf = x_frozen[b0:b1]
+            got = net.hidden_and_last(self.preprocess_fz(xf.float() if xf.dtype == torch.float16 else xf))
             if got is None:
                 return None
             h, last, unit, split = got
@@ -252,6 +256,8 @@ class RQSplineCoupling_(Coupling_):
             return fused
 
         def kernel(v, params, l0, act, layout):
+            if v.dtype == torch.float16 and params.dtype != torch.float16:
+                params = params.half()      # K2's fp16 storage takes x, logits and y as half (fp32 arithmetic and log-det)
             return _hip.RQSCouplingFn.apply(v, params, l0, act, self._opts(params.shape[1], layout, v), inverse)
         return self._run_atom(kernel, x_active, x_frozen, parity, net, log0, 46)
 

@@ -77,6 +77,20 @@ class ConvAct(torch.nn.Sequential):
             raise NotImplementedError("kernel rescaling on transfer is not supported")
         return copy.deepcopy(self)
 
+    # ---- fp16 parameter storage (BASELINE config 5): the kernels compute in fp32 on widened copies, cached per version
+    def _wb(self, conv):
+        w, b = conv.weight, conv.bias
+        if w.dtype != torch.float16:
+            return w, b
+        cache = self.__dict__.setdefault('_w32', {})
+        key = id(conv)
+        ver = (w._version, w.data_ptr(), None if b is None else b._version)
+        hit = cache.get(key)
+        if hit is None or hit[0] != ver:
+            hit = (ver, w.detach().float(), None if b is None else b.detach().float())
+            cache[key] = hit
+        return hit[1], hit[2]
+
     # ---- fused execution: every (conv, activation) pair is ONE launch of the MFMA kernel
     def _plan(self):
         """[(conv module, act code)] if the whole stack maps onto nf_conv_fwd, else None."""
@@ -105,11 +119,14 @@ class ConvAct(torch.nn.Sequential):
 
     def _run_fused(self, x, compact_parity=None):
         plan = self._plan()
-        if plan is None or not _hip.conv_supported(x, plan[0][0].weight) or x.dim() - 2 != self.conv_kwargs['conv_dim']:
+        if plan is not None and plan[0][0].weight.dtype == torch.float16 and x.dtype in (torch.float16, torch.float32):
+            x = x.float()                      # half parameters: fp32 compute on widened copies
+        if plan is None or not _hip.conv_supported(x, self._wb(plan[0][0])[0]) or x.dim() - 2 != self.conv_kwargs['conv_dim']:
             return None
         for n, (conv, act) in enumerate(plan):
             last = n == len(plan) - 1
-            x = _hip.conv_layer(x, conv.weight, conv.bias, act,
+            w, b = self._wb(conv)
+            x = _hip.conv_layer(x, w, b, act,
                                 compact=last and compact_parity is not None,
                                 parity=compact_parity or 0)
         return x
@@ -121,7 +138,14 @@ class ConvAct(torch.nn.Sequential):
         if self.conv_kwargs.get('pre_act') is not None or x.dim() - 2 != self.conv_kwargs['conv_dim']:
             return None
         plan = self._plan()
-        if plan is None or plan[-1][1] != 0 or not _hip.conv_supported(x, plan[0][0].weight):
+        if plan is None or plan[-1][1] != 0:
+            return None
+        # (weight, bias) as the kernels take them: the parameters themselves, or fp32 copies of half parameters
+        import types
+        plan = [(types.SimpleNamespace(weight=w, bias=b), act) for (w, b), act in ((self._wb(conv), act) for conv, act in plan)]
+        if plan[0][0].weight.dtype == torch.float32 and x.dtype == torch.float16:
+            x = x.float()
+        if not _hip.conv_supported(x, plan[0][0].weight):
             return None
         # |hidden| <= 1 when the last hidden activation is tanh or the logistic function: lets the fused kernel use
         # split-fp16 products (nf_conv_h.hip); when it will, the last hidden layer writes its output already split

@@ -1343,3 +1343,99 @@ def test_philox_prior_statistics():
     assert bool(torch.isfinite(xb).all()) and float((xb == 0).float().mean()) < 1e-6
     assert rel(lb, big.log_prob(xb)) <= 1e-5
     assert abs(float(xb.mean())) < 2e-3 and abs(float(xb.std()) - 1) < 2e-3
+
+
+# -------------------------------------------------- BASELINE config 5: fp16 parameters and fields, fp32 log-det
+def test_config5_fp16_storage_mixed_network_48_wide():
+    """Config 5's precision path end to end: a 16-layer mixed network (affine and RQ-spline blocks alternating, ConvAct
+    1-8-8-C, m = 16) on a 48-wide 4-D lattice with fp16 PARAMETERS (net_.to(float16)) and an fp16 FIELD; log|J| accumulates in
+    fp32.  Storage is half, arithmetic fp32: the affine atoms run conv -> nf_affine (NF_F16_FIELD: half field, the fp32
+    parameters the conv layer wrote), the spline atoms the fused conv -> spline kernel with NF_CONV_FIELD_F16 (the logits never
+    exist in memory).  Parity, layer by layer with the oracle's own (half-representable) inputs fed to every layer: the
+    GPU's half output equals the oracle's fp64 result rounded to half up to one half-ulp (where fp32 arithmetic lands on the
+    other side of a rounding boundary) plus the fp32 bound 1e-5 on the value itself (outputs near zero: half's spacing there is
+    far finer than fp32 arithmetic on O(1) terms), on at most 2 % of the sites; the log-det increment matches to 1e-5 relative."""
+    torch.manual_seed(55)
+    shape, B, m = (4, 4, 4, 48), 3, 16
+    mask = EvenOddMask(shape=shape)
+    lim = dict(xlim=(-5.0, 5.0), ylim=(-5.0, 5.0), extrap={'left': 'linear', 'right': 'linear'})
+    blocks = []
+    for i in range(4):
+        for kind in ('affine', 'rqs'):
+            C = 2 if kind == 'affine' else 3 * m - 2
+            nets = [ConvAct(1, C, 3, conv_dim=4, hidden_sizes=[8, 8], acts=['tanh', 'tanh', None]) for _ in range(2)]
+            for net in nets:
+                with torch.no_grad():
+                    for p_ in list(net.parameters())[-2:]:
+                        p_.mul_(0.3)
+            blocks.append(AffineCoupling_(nets, mask=mask) if kind == 'affine' else RQSplineCoupling_(nets, mask=mask, **lim))
+    net_ = ModuleList_(blocks)
+    net_.to(device=DEV, dtype=torch.float16)
+    assert all(p_.dtype == torch.float16 for p_ in net_.parameters())
+    x = torch.randn((B,) + shape, device=DEV, dtype=torch.float32).half()
+    with torch.no_grad():
+        y, lj = net_(x)
+        xb, lb = net_.backward(y, lj)
+    assert y.dtype == torch.float16 and lj.dtype == torch.float32 and bool(torch.isfinite(y).all()) and bool(torch.isfinite(lj).all())
+    assert rel(xb, x) <= 5e-2                 # 16 layers of half storage: each inverse restarts from a field rounded to 11 bits
+    # layer by layer against the oracle, teacher-forced
+    half = lambda t: t.to(torch.float16).to(torch.float64)
+    parts = [half(x.double().cpu() * O.channel_mask(shape, c)) for c in (0, 1)]
+    n_layers, worst_ulp, frac_off = 0, 0.0, 0.0
+    for blk in blocks:
+        kind = 'affine' if isinstance(blk, AffineCoupling_) else 'rqs'
+        atom = O.affine_coupling_atom if kind == 'affine' else O.rqs_coupling_atom
+        opts = {} if kind == 'affine' else lim
+        for k, net in enumerate(blk.nets):
+            p_ = k % 2
+            convs = [mod for mod in net if hasattr(mod, 'weight')]
+            layers = [(c.weight.detach().double().cpu(), c.bias.detach().double().cpu()) for c in convs]
+            out = O.conv_act(parts[1 - p_].unsqueeze(1), layers, ['tanh', 'tanh', None])
+            l0 = torch.randn(B, dtype=torch.float64, device='cpu')
+            yo, lo = atom(parts[p_], out, O.channel_mask(shape, p_), log0=l0, **opts)
+            with torch.no_grad():
+                yg, lg = blk.atomic_forward(x_active=parts[p_].to(DEV, torch.float16), x_frozen=parts[1 - p_].to(DEV, torch.float16),
+                                            parity=p_, net=net, log0=l0.to(DEV, torch.float32))
+            assert yg.dtype == torch.float16 and lg.dtype == torch.float32
+            want = half(yo)
+            diff = (yg.double().cpu() - want).abs()
+            # one half-ulp (the storage rounding may fall on the other side of a boundary) + north_star's fp32 bound on the value
+            ulp = want.abs().clamp_min(2.0 ** -14) * 2.0 ** -10 + 1e-5 * max(1.0, float(want.abs().max()))
+            worst_ulp = max(worst_ulp, float((diff / ulp).max()))
+            frac_off = max(frac_off, float((diff > 0).double().mean()))
+            assert rel(lg, lo) <= 1e-5, (kind, k, rel(lg, lo))
+            parts[p_] = want
+            n_layers += 1
+    assert n_layers == 16
+    assert worst_ulp <= 1.0 + 1e-9 and frac_off <= 0.02, (worst_ulp, frac_off)
+
+
+@pytest.mark.parametrize("layout", ["pair", "full"])
+def test_affine_fp16_storage_fp32_logdet(layout):
+    """nf_affine with fp16 storage (NF_F16: x, params, y half; NF_F16_FIELD: params fp32): the fp32 kernel's result on the same
+    rounded inputs up to the final rounding of y; log|J| fp32 within 1e-6 of the fp64 oracle on those inputs."""
+    torch.manual_seed(8)
+    shape, B = (8, 8, 8, 16), 5
+    V = int(np.prod(shape))
+    for parity in (0, 1):
+        act = O.channel_mask(shape, parity).to(torch.uint8).reshape(-1).to(DEV)
+        x16 = (1.5 * torch.randn(B, V, device=DEV)).half() * act.half()
+        pfull = torch.randn(B, 2, V, device=DEV).half()
+        par16 = compact(pfull, act) if layout == "pair" else pfull
+        lay = _hip.LAYOUT_PAIR if layout == "pair" else _hip.LAYOUT_FULL
+        l0 = torch.randn(B, device=DEV, dtype=torch.float32)
+        for inverse in (False, True):
+            y16, lj = _hip.AffineCouplingFn.apply(x16, par16, l0, act, lay, inverse)                 # NF_F16
+            yf, ljf = _hip.AffineCouplingFn.apply(x16, par16.float(), l0, act, lay, inverse)         # NF_F16_FIELD
+            y32, lj32 = _hip.AffineCouplingFn.apply(x16.float(), par16.float(), l0, act, lay, inverse)
+            assert y16.dtype == torch.float16 and lj.dtype == torch.float32
+            # the fp32 kernel's value rounded to half, up to one half-ulp (the instantiations may contract a*b+c differently)
+            spacing = y32.abs().clamp_min(2.0 ** -14) * 2.0 ** -10
+            for got in (y16, yf):
+                d_ = (got.float() - y32).abs()
+                assert bool((d_ <= spacing).all()) and float((got != y32.half()).float().mean()) < 0.01
+            assert rel(lj, lj32) <= 1e-6 and rel(ljf, lj32) <= 1e-6
+            yo, lo = O.affine_coupling_atom(x16.double().cpu().reshape((B,) + shape), pfull.double().cpu().reshape((B, 2) + shape),
+                                            O.channel_mask(shape, parity), inverse=inverse, log0=l0.double().cpu())
+            assert rel(lj, lo) <= 1e-6
+            assert rel(y16, yo.reshape(B, V)) <= 1e-3
