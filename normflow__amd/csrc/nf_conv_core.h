@@ -96,6 +96,18 @@ __device__ __forceinline__ void store_field_pair(const ConvArgs &A, int64_t pair
   else reinterpret_cast<float2 *>(A.yout)[pair] = v;
 }
 
+// One LDS-DMA piece: 64 lanes x 16 bytes from sbase + voff (per lane) to the 1 KiB at LDS byte address `lds` (wave-uniform).
+// M0 is written in the same statement that reads it and is not restored: nothing else in this kernel uses it (checked in the
+// ISA), and a save / restore pair per piece bought nothing.
+__device__ __forceinline__ void dma_row(const void *sbase, unsigned voff, unsigned lds) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 // tanh on the hardware exp/rcp: (1 - t) / (1 + t), t = exp(-2|v|); absolute error ~1e-7 (the fp32 rounding of an
 // O(1) activation), ~8 instructions where ocml's tanhf takes ~40 -- it was most of the 8->8 layer's epilogue.
 __device__ __forceinline__ float fast_tanh(float v) {

@@ -50,18 +50,6 @@ constexpr float kInvWScale = 1.0f / 1024.0f;  // the weights are packed scaled b
 static_assert(LDS_BYTES <= 160 * 1024, "ring + exchange must fit the CU's LDS");
 }  // namespace g2
 
-// One LDS-DMA piece: 64 lanes x 16 bytes from sbase + voff (per lane) to the 1 KiB at LDS byte address `lds` (wave-uniform).
-// M0 is written in the same statement that reads it and is not restored: nothing else in this kernel uses it (checked in the
-// ISA), and a save / restore pair per piece bought nothing.
-__device__ __forceinline__ void dma_row(const void *sbase, unsigned voff, unsigned lds) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
 // tanh(v) for v = a * scale + bias given as (a, c1 = 2 log2(e) scale, c0 = 2 log2(e) bias): 1 - 2 / (1 + 2^(c1 a + c0)); five
 // instructions, two of them transcendental; absolute error ~1e-7 (the rounding of a number near 1), exact limits at +-inf.
 __device__ __forceinline__ float tanh_affine(float a, float c1, float c0) {

@@ -35,14 +35,14 @@ namespace h {
 constexpr int H0 = 4, H1 = 4, H2 = 4;                     // halo rows of a 2x2x2x32 box under a 3^4 kernel; the box spans the fastest axis
 constexpr int L3 = 32;                                    // (periodic): its two halo sites are the row's own end sites -- by address, not by copy
 constexpr int NROW = H0 * H1 * H2;                        // 64 halo rows: one per lane of the loader wave
-// An image (8 channels = 16 bytes per site, hi or lo halves) is two sub-images [parity of the site x3][row][16 entries of
-// 16 bytes]: the 16 lanes of a k-group of an A fragment (v_mfma_f32_16x16x32_f16: k-group g = the 8 channels of ONE tap)
-// read sites x3 = 2p + c - 1 mod 32 of one parity, i.e. the 16 entries of a row, rotated: 256 contiguous bytes, no bank
-// conflict.  (In plain site order the same read strides 32 bytes: a 4-way conflict, measured 35 instead of ~18 cycles
-// per MFMA.)
-constexpr int ROWB = 16 * 16;                             // bytes of a row in a sub-image
-constexpr int SUB = NROW * ROWB;                          // 16384
-constexpr int IMG = 2 * SUB;                              // bytes of one fp16 image
+// The LDS image of an item is the row-major pair layout itself (pair_row_offset, nf_conv_core.h): 64 halo rows of 1 KiB =
+// [hi | lo][even sites | odd sites][16 slots x 16 B]; the mover fills it by LDS-DMA, one row (1 KiB, contiguous in the pair
+// tensor) per wave-instruction -- no staging registers and no ds_write on the way.  The 16 lanes of a k-group of an A fragment
+// (v_mfma_f32_16x16x32_f16: k-group g = the 8 channels of ONE tap) read sites x3 = 2p + c - 1 mod 32 of one parity, i.e. the 16
+// slots of a parity block, rotated: 256 contiguous bytes, no bank conflict.  (In plain site order the same read strides 32
+// bytes: a 4-way conflict, measured 35 instead of ~18 cycles per MFMA.)
+constexpr int RB = L3 * 32, HB = L3 * 16;                 // bytes of a row image / of its hi block
+constexpr int ITEM = NROW * RB;                           // 64 KiB: one item's image (hi and lo)
 __host__ __device__ constexpr int rowidx(int r) { return ((r / 9) * H1 + (r / 3) % 3) * H2 + r % 3; }   // kernel row -> halo row step
 // K slices of 32 = (4 kernel rows) x (8 channels) at ONE tap j3 of the fastest axis: slice sl = 7*j3 + i holds kernel
 // rows 4i .. 4i+3 (row 27 is padding: zero weights).  Same j3 for the four k-groups => same parity sub-image.
@@ -53,8 +53,8 @@ constexpr int C = 46, M = 16;
 constexpr int PTS = UNITS + 4;                            // row stride of the logit scratch in floats: +4 spreads the 16 channels a
                                                           // wave writes at once over the banks (stride 128 put them all on one)
 constexpr int PT = C * PTS * 4;                           // bytes of the logit scratch
-constexpr int LDS_BYTES = 4 * IMG + PT;
-static_assert(2 * PT <= 2 * IMG, "two planes of partial sums must fit a consumed image");
+constexpr int LDS_BYTES = 2 * ITEM + PT;
+static_assert(2 * PT <= ITEM, "two planes of partial sums must fit a consumed image");
 static_assert(LDS_BYTES <= 160 * 1024, "two image pairs and the logit scratch must fit the CU's LDS");
 
 }  // namespace h
@@ -144,19 +144,19 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     // byte offset of this lane's A read = T[site tile] + RG[i]: T places the lane's site (box row mt: z0 = mt>>2,
     // z1 = (mt>>1)&1, z2 = mt&1; halo index 2p + parity + j3) in its parity sub-image, RG adds the halo rows of kernel
     // row 4i + g.  Box extents are even, so the parity of a box row does not depend on the box.
-    int TP[2], RG[7];        // T[mt] = TP[(z0 + z1 + z2) & 1] + r0(mt) * ROWB, the second term a compile-time offset
+    int TP[2], RG[7];        // T[mt] = TP[(z0 + z1 + z2) & 1] + r0(mt) * RB, the second term a compile-time offset
     {
       const int p = lane & 15;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int x3 = (2 * p + ((A.parity + e) & 1) + W - 1) & (L3 - 1);      // tap W of active site p, wrapped
-        TP[e] = (x3 & 1) * SUB + (x3 >> 1) * 16;
+        TP[e] = pair_row_offset(x3, L3);
       }
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
         const int r = 4 * i + g;
         const int rr = r < 27 ? r : 26;
-        RG[i] = (((rr / 9) * H1 + (rr / 3) % 3) * H2 + rr % 3) * ROWB;
+        RG[i] = (((rr / 9) * H1 + (rr / 3) % 3) * H2 + rr % 3) * RB;
       }
     }
     // The three partial sums of a column tile: slot 0 (the wave's OWN column tile, w) stays in the accumulators; slots 1 and
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     for (int k = 0; k < 3; ++k) {
       const int co = (((W + k) % 3) << 4) + (lane & 15);
       okk[k] = co < C;
-      ptk[k] = lds0 + ((okk[k] ? co : 0) * PTS + (g << 2)) * 4 + (k == 0 ? 4 * IMG : (k - 1) * PT);
+      ptk[k] = lds0 + ((okk[k] ? co : 0) * PTS + (g << 2)) * 4 + (k == 0 ? 2 * ITEM : (k - 1) * PT);
     }
     const int home = (((W << 4) + (lane & 15)) * PTS + (g << 2)) * 4;      // byte offset of this lane's unit quad (site tile 0) in a plane, own column tile
     f32x4 acc0;               // what slot 0 starts from
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
 #endif
     lds_barrier();            // P: the mover has staged the first image
     for (int m = 0; m < n_my; ++m) {
-      const int ioff = (m & 1) * 2 * IMG;
+      const int ioff = (m & 1) * ITEM;
       const unsigned char *img[2] = {smem_h + ioff + TP[0], smem_h + ioff + TP[1]};
       auto fetch = [&](auto QC) {
         constexpr int qs = decltype(QC)::value;
@@ -199,9 +199,9 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
         for (int t = 0; t < 2; ++t) {
           const int mt = t0 + t;
           const int z0 = mt >> 2, z1 = (mt >> 1) & 1, z2 = mt & 1;
-          const unsigned char *src = img[(z0 + z1 + z2) & 1] + RG[i] + ((z0 * H1 + z1) * H2 + z2) * ROWB;
+          const unsigned char *src = img[(z0 + z1 + z2) & 1] + RG[i] + ((z0 * H1 + z1) * H2 + z2) * RB;
           fa[q][t] = *reinterpret_cast<const f16x8 *>(src);
-          fl[q][t] = *reinterpret_cast<const f16x8 *>(src + IMG);
+          fl[q][t] = *reinterpret_cast<const f16x8 *>(src + HB);
         }
       };
       auto mult = [&](auto QC) {
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       if (okk[0]) {
         typedef __attribute__((address_space(3))) f32x4 lds_q;
         const lds_f *pa = (const lds_f *)(smem_h + ioff + home);       // plane 1, this lane's channel and unit quad of site tile 0
-        lds_f *po = (lds_f *)(smem_h + 4 * IMG + home);
+        lds_f *po = (lds_f *)(smem_h + 2 * ITEM + home);
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
           const f32x4 s1 = *(const lds_q *)(pa + (mt << 4));
@@ -297,9 +297,9 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   const int rs = lane >> 5, xs = lane & 31;
   const bool pre = A.in_split16 != 0;       // input already split (flag carried in the high bits of dbg)
   auto put = [&](unsigned char *imgH, int row, int x3, const f16x8 &hi, const f16x8 &lo) {
-    const int d = (x3 & 1) * SUB + row * ROWB + (x3 >> 1) * 16;
+    const int d = row * RB + pair_row_offset(x3, L3);
     *reinterpret_cast<f16x8 *>(imgH + d) = hi;
-    *reinterpret_cast<f16x8 *>(imgH + IMG + d) = lo;
+    *reinterpret_cast<f16x8 *>(imgH + HB + d) = lo;
   };
   auto put3 = [&](unsigned char *imgH, int row, const f16x8 &hi, const f16x8 &lo) { put(imgH, row, xs, hi, lo); };
   auto stage = [&](int b, const int (&o)[4], unsigned char *imgH) {
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     for (int pass = 0; pass < 2; ++pass) xpre[pass] = load_field_pair(A, pair_of(b, o, pass));
   };
   auto epilogue = [&](int b, const int (&o)[4], int64_t pidx) {
-    const lds_f *ptl = (const lds_f *)(smem_h + 4 * IMG);
+    const lds_f *ptl = (const lds_f *)(smem_h + 2 * ITEM);
     double lacc = 0.0;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -405,59 +405,56 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   int cb, co4[4];
   decode(vb, cb, co4);
   stage(cb, co4, smem_h);
-  // Pre-split input: the 64 16-byte loads of a whole item live in registers from one iteration to the next -- issued
-  // after item m+1 has been committed, committed after the epilogue of the following iteration -- so the copy never
-  // waits for memory.  (fp32 input keeps the in-iteration staging above: it is the fallback, not the pipeline's path.)
-  f16x8 qh[NROW / 2], ql[NROW / 2];
-  const unsigned xoff = unsigned(pair_row_offset(xs, L3));
-  auto issue_item = [&](int b, const int (&o)[4]) {
-    const int myoff = row_offsets(o);
-    // uniform 64-bit base + 32-bit per-lane byte offset (a sample is V*32 < 2^32 bytes): scalar-base addressing
-    const unsigned char *__restrict__ src = static_cast<const unsigned char *>(A.in) + int64_t(b) * A.V * 32;
+  // Pre-split input (the pipeline's path): the next item's image is brought in by LDS-DMA, one halo row = one 1 KiB piece =
+  // one wave-instruction (the pair tensor's rows ARE the image rows): no staging registers, no ds_write -- the mover's 128
+  // 16-byte LDS stores per item used to take ~13 % of the kernel from the compute waves' fragment reads.
+  const unsigned lds0m = unsigned(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char *)smem_h));
+  const unsigned lane16 = unsigned(lane * 16);
+  int dma_off = 0;                              // lane l: site offset of halo row l of the item being brought in
+  const unsigned char *dma_src = nullptr;
+  auto dma_open = [&](int b, const int (&o)[4]) {
+    dma_off = row_offsets(o);
+    dma_src = static_cast<const unsigned char *>(A.in) + int64_t(b) * A.V * 32;
+  };
+  auto dma_rows = [&](unsigned buf, auto R0, auto R1) {     // halo rows [R0, R1) -> image buffer at LDS byte address buf
+    constexpr int r0 = decltype(R0)::value, r1 = decltype(R1)::value;
 #pragma unroll
-    for (int i = 0; i < NROW / 2; ++i) {
-      const unsigned oa = unsigned(__builtin_amdgcn_readlane(myoff, 2 * i));
-      const unsigned ob = unsigned(__builtin_amdgcn_readlane(myoff, 2 * i + 1));
-      const unsigned voff = (rs ? ob : oa) * 32u + xoff;            // row start (row-major pair layout) + this lane's site
-      qh[i] = *reinterpret_cast<const f16x8 *>(src + voff);
-      ql[i] = *reinterpret_cast<const f16x8 *>(src + voff + unsigned(L3 * 16));
+    for (int i = r0; i < r1; ++i) {
+      const unsigned ro = unsigned(__builtin_amdgcn_readlane(dma_off, i));
+      dma_row(dma_src + uint64_t(ro) * 32u, lane16, buf + unsigned(i * RB));
     }
   };
-  // lane-constant part of the LDS address (row = 2i + rs); per pass only an immediate row offset is added
-  const int d_main = (xs & 1) * SUB + rs * ROWB + (xs >> 1) * 16;
-  auto commit_item = [&](unsigned char *imgH) {
-#pragma unroll
-    for (int i = 0; i < NROW / 2; ++i) {
-      unsigned char *p0 = imgH + d_main + i * (2 * ROWB);
-      *reinterpret_cast<f16x8 *>(p0) = qh[i];
-      *reinterpret_cast<f16x8 *>(p0 + IMG) = ql[i];
-    }
-  };
-  int n1b = cb, n1o[4] = {co4[0], co4[1], co4[2], co4[3]};      // item m + 1 (in registers when pre)
+  int n1b = cb, n1o[4] = {co4[0], co4[1], co4[2], co4[3]};      // item m + 1
   if (n_my > 1) advance(n1b, n1o);
-  if (pre && n_my > 1) issue_item(n1b, n1o);
   prefetch_x(cb, co4);
   lds_barrier();                                // P: image 0 ready
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, NROW / 2> IH;
+  typedef std::integral_constant<int, NROW> IN;
   for (int m = 0; m < n_my; ++m) {
     if (m > 0 && !NF_DBG(A, 128)) epilogue(pb, po, int64_t(vb) + int64_t(m - 1) * nb);     // dbg 128: timing ablation
     prefetch_x(cb, co4);                        // for the epilogue of item m, one iteration from now
-    int n2b = n1b, n2o[4] = {n1o[0], n1o[1], n1o[2], n1o[3]};
-    if (m + 2 < n_my) advance(n2b, n2o);
-    // image m+1 goes where image m-1 and then the partial sums of item m-1 were: after the epilogue above
-    if (m + 1 < n_my && !NF_DBG(A, 64)) {        // dbg 64: timing ablation
-      if (pre) { if (!NF_DBG(A, 512)) commit_item(smem_h + ((m + 1) & 1) * 2 * IMG); }     // dbg 512: timing ablation, loads only
-      else stage(n1b, n1o, smem_h + ((m + 1) & 1) * 2 * IMG);
+    // image m+1 goes where image m-1 and then the partial sums of item m-1 were: after the epilogue above.  Half of its
+    // rows are issued here, half behind B1 (while the compute waves store and add: this wave has nothing else to do then)
+    const bool more = m + 1 < n_my && !NF_DBG(A, 64);          // dbg 64: timing ablation
+    const unsigned nbuf = lds0m + unsigned(((m + 1) & 1) * ITEM);
+    if (more) {
+      if (pre) {
+        dma_open(n1b, n1o);
+        dma_rows(nbuf, I0{}, IH{});
+      } else {
+        stage(n1b, n1o, smem_h + ((m + 1) & 1) * ITEM);
+      }
     }
-    lds_barrier();                              // B1: image m is consumed, pt is free (committing the next image after this
-                                                //     barrier instead, in the store/add window, was measured: +9 %)
-    // the loads of item m+2 go out while the compute waves store and add: this wave has nothing else to do until Bs
-    if (m + 2 < n_my && pre && !NF_DBG(A, 64)) issue_item(n2b, n2o);
+    lds_barrier();                              // B1: image m is consumed, pt is free
+    if (more && pre) dma_rows(nbuf, IH{}, IN{});
     pb = cb;
     cb = n1b;
-    n1b = n2b;
 #pragma unroll
-    for (int mu = 0; mu < 4; ++mu) { po[mu] = co4[mu]; co4[mu] = n1o[mu]; n1o[mu] = n2o[mu]; }
+    for (int mu = 0; mu < 4; ++mu) { po[mu] = co4[mu]; co4[mu] = n1o[mu]; }
+    if (m + 2 < n_my) advance(n1b, n1o);
     lds_barrier();                              // B2: the partial sums of item m are in pt and in image m
+    if (pre) wait_vm<0>();                      // image m+1 has landed (a whole MFMA phase after its first row was issued)
     lds_barrier();                              // Bs: the compute waves have added them up: logits of item m in pt
   }
   epilogue(pb, po, int64_t(vb) + int64_t(n_my - 1) * nb);

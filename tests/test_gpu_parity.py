@@ -1439,3 +1439,35 @@ def test_affine_fp16_storage_fp32_logdet(layout):
                                             O.channel_mask(shape, parity), inverse=inverse, log0=l0.double().cpu())
             assert rel(lj, lo) <= 1e-6
             assert rel(y16, yo.reshape(B, V)) <= 1e-3
+
+
+def test_graph_replay_survives_larger_eager_calls():
+    """a captured graph bakes raw scratch pointers in.  The per-workgroup log-det partials come from torch's
+    caching allocator per call (graph-pool safe), so a replay after LARGER eager calls and unrelated allocations still
+    writes into memory the graph owns: results stay bitwise equal to an eager pass."""
+    from normflow__amd import GraphedFlow
+    torch.manual_seed(77)
+    shape = (8, 8)
+    mask = EvenOddMask(shape=shape)
+    mk = lambda c: ConvAct(1, c, 3, conv_dim=2, hidden_sizes=[4], acts=['tanh', None]).to(DEV, torch.float32)
+    lim = dict(xlim=(-4.0, 4.0), ylim=(-4.0, 4.0), extrap={'left': 'linear', 'right': 'linear'})
+    net_ = ModuleList_([AffineCoupling_([mk(2), mk(2)], mask=mask), RQSplineCoupling_([mk(22), mk(22)], mask=mask, **lim)]).to(DEV)
+    xs = torch.randn((4,) + shape, device=DEV, dtype=torch.float32)
+    g = GraphedFlow(net_, xs)
+    with torch.no_grad():
+        y0, l0 = net_(xs)
+        big = torch.randn((4096,) + shape, device=DEV, dtype=torch.float32)
+        for _ in range(3):
+            net_(big)                                        # needs far more scratch than the captured pass
+        junk = [torch.full((1 << 20,), float(i), device=DEV, dtype=torch.float32) for i in range(16)]      # churn the allocator
+        del junk
+        net_(big[:1000])
+    y1, l1 = g(xs)
+    assert torch.equal(y1, y0) and torch.equal(l1, l0)
+    # after an optimizer-like in-place weight change the graph re-captures (the kernel choice was validated for the old values)
+    with torch.no_grad():
+        for p_ in net_.parameters():
+            p_.mul_(1.01)
+        y2, l2 = net_(xs)
+    y3, l3 = g(xs)
+    assert torch.equal(y3, y2) and torch.equal(l3, l2) and not torch.equal(y3, y0)
