@@ -205,7 +205,7 @@ def time_hidden_layers(cpl, lattice, dev, reps, batch):
     f0 = lambda: _hip.conv_layer(x, c0.weight.detach(), c0.bias.detach(), tanh, compact=2 if chain else False)
     ms0 = _events_ms(f0, reps)
     by0 = slab * V * (4 + 32)
-    out.append({"kernel": "first ConvAct layer 1->8 + tanh (nf::conv_c1_kernel)" + (", fp16 (hi,lo) pair output" if chain else ""),
+    out.append({"kernel": "first ConvAct layer 1->8 + tanh (nf::conv_c2_kernel, split-fp16 products)" + (", fp16 (hi,lo) pair output" if chain else ""),
                 "bound": "hbm", "achieved": by0 / ms0 / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": by0 / ms0 / 1e6 / HBM_PEAK_GBS, "launch_ms": ms0, "slab_batch": slab,
                 "algorithmic_bytes_per_launch": by0, "traffic": None})
@@ -213,7 +213,7 @@ def time_hidden_layers(cpl, lattice, dev, reps, batch):
     if chain:
         h16 = f0()
         f1 = lambda: _hip.conv_layer_split16(h16, c1.weight.detach(), c1.bias.detach(), tanh, tuple(lattice))
-        peak, name = MFMA_F16_PEAK_TFLOPS / 3.0, "hidden ConvAct layer 8->8 + tanh (nf::conv_g_kernel, split-fp16 products)"
+        peak, name = MFMA_F16_PEAK_TFLOPS / 3.0, "hidden ConvAct layer 8->8 + tanh (nf::conv_g2_kernel, split-fp16 products)"
     else:
         hin = torch.tanh(torch.randn((slab, hidden) + tuple(lattice), device=dev, dtype=torch.float32, generator=g))
         f1 = lambda: _hip.conv_layer(hin, c1.weight.detach(), c1.bias.detach(), tanh)
@@ -257,10 +257,10 @@ def profiled_traffic(kernel_key, slab, lattice, knots):
         if tuple(prof.get("lattice", ())) != tuple(lattice) or prof.get("knots") != knots:
             reason = f"{name}: profiled on another workload"
             continue
-        k = prof.get("kernels", {}).get(kernel_key)
-        if not k:
+        k = next((v for kn, v in prof.get("kernels", {}).items() if kernel_key in kn), None)
+        if not k or "traffic_bytes_per_launch" not in k:
             continue
-        return k["traffic_bytes_per_launch"] * slab / prof["slab_batch"], f"profiles/{name}"
+        return k["traffic_bytes_per_launch"] * slab / k.get("slab_batch", prof.get("slab_batch", slab)), f"profiles/{name}"
     return None, reason
 
 
@@ -466,7 +466,7 @@ def main():
                         "launch_ms": 1e3 * ft["seconds"], "slab_batch": ft["slab"],
                         "algorithmic_flops_per_launch": ft["flops"]}
             others = time_hidden_layers(cpl, lattice, dev, reps, a.batch)
-            for o, key in zip(others, ("conv_c1_kernel", "conv_g_kernel")):
+            for o, key in zip(others, ("conv_c2_kernel", "conv_g2_kernel")):
                 o["traffic"], o["traffic_source"] = profiled_traffic(key, o["slab_batch"], lattice, a.knots)
         else:
             roof = hbm_obj

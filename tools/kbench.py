@@ -17,6 +17,10 @@ a = ap.parse_args()
 dev = torch.device("cuda", 0)
 lattice = tuple(int(s) for s in a.lattice.split(","))
 net_, cpl = bench.build_net(lattice, 2, 16, dev, seed=2024)
+if a.only == "k2":
+    kt = bench.time_rqs_kernel(cpl, lattice, 16, dev, a.reps, True)
+    print(f"[kbench {a.tag}] K2 slab {kt['slab']} {1e3*kt['seconds']:.3f} ms  {kt['gbs']:.0f} GB/s", flush=True)
+    sys.exit(0)
 if a.only in ("g", "c"):
     oth = bench.time_hidden_layers(cpl, lattice, dev, a.reps, a.batch)
     print(f"[kbench {a.tag}] K5g {oth[1]['launch_ms']:.3f} ms  K5c {oth[0]['launch_ms']:.3f} ms", flush=True)
