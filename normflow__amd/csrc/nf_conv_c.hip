@@ -27,13 +27,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace c2 {
-constexpr int L3 = 32;
-constexpr int RB = L3 * 32, HB = L3 * 16;     // output row bytes / its hi block
+constexpr int SEG = 32;                       // sites of a SEGMENT of the fastest axis: one MFMA tile of 16 pairs.  A lattice row of L3
+                                              // sites is ceil(L3 / 32) segments; a column of the march is (cross-section, segment)
 #ifndef NF_C2_IROW
 #define NF_C2_IROW 80
 #endif
 constexpr int IROW = NF_C2_IROW;                      // bytes of an input row image: 34 halves (sites -1 .. 32) + pad, 8-byte multiple;
-                                              // 80 = 20 dwords: consecutive rows start 20 banks apart
+                                              // (positions 0 .. 33 = sites 32 h - 1 .. 32 h + 32 of segment h, periodic in L3)
 constexpr int MAXROWS = 36;                   // (4 + 2) x (4 + 2) halo rows of a plane
 constexpr int PLANE = 2 * MAXROWS * IROW;     // hi image + lo image of one plane: 5760 B
 constexpr int NPL = 4;                        // ring: planes z-1, z, z+1 being read + one being written
@@ -57,15 +57,19 @@ __global__ __launch_bounds__(512, 2) void conv_c2_kernel(ConvArgs A) {
   const int H1 = C1 + 2, NROWS = (C0 + 2) * H1;           // halo rows of a plane
   const int NT = C0 * C1;                                 // tiles (output rows) per plane
   const int n0 = A.L[0] / C0, n1 = A.L[1] / C1, ncol = n0 * n1;
-  const int L2 = A.L[2];
-  const int total = int(A.nitems);                        // B * ncol columns
+  const int L2 = A.L[2], L3 = A.L[3];
+  const int RB = L3 * 32, HB = L3 * 16;                    // bytes of an output row of the pair tensor / of its hi block
+  const int HP = L3 >> 1, NSEG = (HP + 15) >> 4;           // pairs per row; segments per row
+  const int total = int(A.nitems);                        // B * ncol * NSEG columns
   const int nwg = gridDim.x;
   // my columns: blockIdx, blockIdx + nwg, ...  (a column of this layer reads 4 B and writes 32 B per site: no halo traffic to
   // speak of, so no XCD-aware grouping is needed)
   if (int(blockIdx.x) >= total) return;
   const int ncols_my = (total - int(blockIdx.x) + nwg - 1) / nwg;
-  auto decode = [&](int ci, int &b, int &i0, int &i1) {
-    const int gc = int(blockIdx.x) + ci * nwg;
+  auto decode = [&](int ci, int &b, int &i0, int &i1, int &hs) {
+    int gc = int(blockIdx.x) + ci * nwg;
+    hs = gc % NSEG;
+    gc /= NSEG;
     b = gc / ncol;
     const int c = gc - b * ncol;
     i0 = c / n1;
@@ -105,24 +109,34 @@ __global__ __launch_bounds__(512, 2) void conv_c2_kernel(ConvArgs A) {
       roff[sl][h] = ((r / 9) * H1 + (r / 3) % 3) * IROW + 4 * p;
     }
 
-  // ---- staging: the halo rows of a plane are spread over the threads, one float per thread and pass: row = id / 32, site = id % 32
-  const int NPASS = (NROWS * 32 + 511) / 512;  // <= 3
+  // ---- staging: the 34 positions of every halo row of a plane are spread over the threads, one float per thread and pass:
+  // row = id / 34, position = id % 34 = site 32 hs - 1 + position of the row (mod L3)
+  constexpr int NPOS = SEG + 2;
+  const int NPASS = (NROWS * NPOS + 511) / 512;  // <= 3 (36 rows x 34 = 1224)
   const float *__restrict__ inb = static_cast<const float *>(A.in);
   float sv[3] = {0.f, 0.f, 0.f};               // loads in flight (issued for plane z+2, committed one step later)
-  // per-thread constant part of the source index (row coordinates), recomputed per column
-  int srow[3] = {0, 0, 0};                     // (x0 * L1 + x1) * L2 * L3 + site of this thread's element in pass k, -1 = none
+  int srow[3] = {0, 0, 0};                     // element index of this thread's site at plane 0 in pass k, -1 = none; per column
+  int sdst[3] = {0, 0, 0};                     // its byte offset in a plane's hi image
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int id = k * 512 + int(threadIdx.x);
+    const int row = id / NPOS, pos = id - row * NPOS;
+    sdst[k] = row * IROW + pos * 2;
+  }
   auto open_stage_column = [&](int ci) {
-    int b, i0, i1;
-    decode(ci, b, i0, i1);
+    int b, i0, i1, hs;
+    decode(ci, b, i0, i1, hs);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int id = k * 512 + int(threadIdx.x);
-      const int row = id >> 5, site = id & 31;
+      const int row = id / NPOS, pos = id - row * NPOS;
       if (k < NPASS && row < NROWS) {
         const int hz0 = row / H1, hz1 = row - hz0 * H1;
         int x0 = C0 * i0 + hz0 - 1, x1 = C1 * i1 + hz1 - 1;
         x0 = x0 < 0 ? x0 + A.L[0] : (x0 >= A.L[0] ? x0 - A.L[0] : x0);
         x1 = x1 < 0 ? x1 + A.L[1] : (x1 >= A.L[1] ? x1 - A.L[1] : x1);
+        int site = SEG * hs + pos - 1;
+        site = site < 0 ? site + L3 : (site >= L3 ? site - L3 : site);           // (32 hs + 32 <= L3 + 16: one wrap is enough)
         srow[k] = ((b * A.L[0] + x0) * A.L[1] + x1) * (L2 * L3) + site;      // < 2^31: checked by the launcher
       } else {
         srow[k] = -1;
@@ -139,28 +153,23 @@ __global__ __launch_bounds__(512, 2) void conv_c2_kernel(ConvArgs A) {
     unsigned char *ph = smem_c2 + slot * PLANE;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const int id = k * 512 + int(threadIdx.x);
-      const int row = id >> 5, site = id & 31;
-      if (k < NPASS && row < NROWS) {
+      if (k < NPASS && srow[k] >= 0) {
         const _Float16 h = static_cast<_Float16>(sv[k]);
         const _Float16 l = static_cast<_Float16>(sv[k] - static_cast<float>(h));
-        _Float16 *rh = reinterpret_cast<_Float16 *>(ph + row * IROW);
-        _Float16 *rl = reinterpret_cast<_Float16 *>(ph + MAXROWS * IROW + row * IROW);
-        rh[site + 1] = h;
-        rl[site + 1] = l;
-        if (site == 0) { rh[L3 + 1] = h; rl[L3 + 1] = l; }          // periodic copies: position 33 = site 0
-        if (site == L3 - 1) { rh[0] = h; rl[0] = l; }               //                  position 0 = site 31
+        *reinterpret_cast<_Float16 *>(ph + sdst[k]) = h;
+        *reinterpret_cast<_Float16 *>(ph + MAXROWS * IROW + sdst[k]) = l;
       }
     }
   };
 
-  // ---- epilogue addressing (as nf_conv_g.hip)
-  const unsigned lane_o = unsigned(pair_row_offset(2 * p + (g >> 1), L3) + (g & 1) * 8);
+  // ---- epilogue addressing: lane (p, g) ends up with channels 4 (g & 1) .. + 3 of site 2 q + (g >> 1), q = 16 hs + p its pair
   unsigned char *__restrict__ outb = static_cast<unsigned char *>(A.out);
   const int64_t sampleB = A.V * 32;
   // my tiles of a plane: rows zt = wave and wave + 8 of the cross-section (row-major (z0, z1))
   int tz[2], toff[2];
   unsigned char *ocol[2] = {nullptr, nullptr};
+  unsigned lane_o = 0;
+  bool lane_ok = true;                         // my pair exists (a partial last segment has 8 of 16)
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     tz[t] = wave + 8 * t;
@@ -168,8 +177,11 @@ __global__ __launch_bounds__(512, 2) void conv_c2_kernel(ConvArgs A) {
     toff[t] = (z0 * H1 + z1) * IROW;
   }
   auto open_column = [&](int ci) {
-    int b, i0, i1;
-    decode(ci, b, i0, i1);
+    int b, i0, i1, hs;
+    decode(ci, b, i0, i1, hs);
+    const int q = 16 * hs + p;
+    lane_ok = q < HP;
+    lane_o = unsigned(pair_row_offset(lane_ok ? 2 * q + (g >> 1) : 0, L3) + (g & 1) * 8);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int z0 = tz[t] / C1, z1 = tz[t] - z0 * C1;
@@ -265,9 +277,11 @@ __global__ __launch_bounds__(512, 2) void conv_c2_kernel(ConvArgs A) {
             hi[r] = h0;
             lo[r] = static_cast<_Float16>(v - static_cast<float>(h0));
           }
-          unsigned char *d = ocol[t] + unsigned(z) * unsigned(RB) + lane_o;
-          *reinterpret_cast<f16x4 *>(d) = hi;
-          *reinterpret_cast<f16x4 *>(d + HB) = lo;
+          if (lane_ok) {
+            unsigned char *d = ocol[t] + unsigned(z) * unsigned(RB) + lane_o;
+            *reinterpret_cast<f16x4 *>(d) = hi;
+            *reinterpret_cast<f16x4 *>(d + HB) = lo;
+          }
         }
       }
     }
@@ -283,14 +297,14 @@ __global__ __launch_bounds__(512, 2) void conv_c2_kernel(ConvArgs A) {
 
 using namespace nf;
 
-// 1 if nf_conv_first_split16 takes this layer: 1 -> 8 channels, 3^4 kernel, 32-site fastest axis, even other extents,
+// 1 if nf_conv_first_split16 takes this layer: 1 -> 8 channels, 3^4 kernel, a fastest axis of 32, 48, 64, ... sites (a multiple of 16), even other extents,
 // an activation that keeps |out| <= 1.
 extern "C" int nf_conv_first_split16_supported(const int32_t *lattice, const int32_t *ksize, int cout, int act) {
   if (!nf::option(NF_OPT_SPLIT16) || !lattice || !ksize || cout != 8) return 0;
   if (act != kActTanh && act != kActSigmoid) return 0;
   for (int mu = 0; mu < 4; ++mu)
     if (ksize[mu] != 3) return 0;
-  if (lattice[3] != c2::L3) return 0;
+  if (lattice[3] < 32 || (lattice[3] & 15)) return 0;                     // whole or half segments of 32 sites
   for (int mu = 0; mu < 3; ++mu)
     if (lattice[mu] < 2 || (lattice[mu] & 1)) return 0;
   return 1;
@@ -301,7 +315,7 @@ extern "C" int nf_conv_first_split16(const void *in, const void *wsplit, const v
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   NF_REQUIRE(in && wsplit && out16 && lattice, "nf_conv_first_split16: NULL pointer");
   const int32_t k3[4] = {3, 3, 3, 3};
-  NF_REQUIRE(nf_conv_first_split16_supported(lattice, k3, 8, act), "nf_conv_first_split16: layer not supported (needs a 32-site fastest axis, even other extents, tanh / sigmoid)");
+  NF_REQUIRE(nf_conv_first_split16_supported(lattice, k3, 8, act), "nf_conv_first_split16: layer not supported (needs a fastest axis of 32 + 16 n sites, even other extents, tanh / sigmoid)");
   NF_REQUIRE(B >= 0 && B <= 65535, "nf_conv_first_split16: batch outside [0, 65535]");
   if (B == 0) return NF_OK;
   ConvArgs A{};
@@ -314,7 +328,7 @@ extern "C" int nf_conv_first_split16(const void *in, const void *wsplit, const v
   A.cin = 1; A.cout = 8; A.act = act;
   A.box[0] = lattice[0] % 4 == 0 ? 4 : 2;                              // cross-section of a column
   A.box[1] = lattice[1] % 4 == 0 ? 4 : 2;
-  A.nitems = B * int64_t(lattice[0] / A.box[0]) * int64_t(lattice[1] / A.box[1]);
+  A.nitems = B * int64_t(lattice[0] / A.box[0]) * int64_t(lattice[1] / A.box[1]) * int64_t((lattice[3] / 2 + 15) / 16);   // columns x segments
   NF_REQUIRE(B * A.V < (int64_t(1) << 31), "nf_conv_first_split16: batch x volume >= 2^31 sites, split the batch");
   static int ncu = 0;
   if (!ncu) {

@@ -37,17 +37,24 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #endif
 
 namespace g2 {
-constexpr int L3 = 32;                        // sites of the fastest axis (a lattice row = one MFMA tile of 16 pairs)
-constexpr int RB = L3 * 32, HB = L3 * 16, PB = L3 * 8;      // bytes of a row / of its hi block / of a parity block
-constexpr int PLROWS = 16;                    // halo rows of a plane: (z0, z1) in {-1..2}^2, row index 4*hz0 + hz1
-constexpr int PLANE = PLROWS * RB;            // 16 KiB
-constexpr int NSLOT = 8;                      // ring: 4 planes being read + 4 ahead
-constexpr int RING = NSLOT * PLANE;           // 128 KiB
-constexpr int XBUF = 4 * 2 * 64 * 16;         // partial-sum exchange: [wave pair][direction][lane] x 16 B, one of two buffers
-constexpr int LDS_BYTES = RING + 2 * XBUF;                  // 131072 + 16384 = 147456 <= 163840
+// A lattice row of L3 sites is cut into SEGMENTS of 32 sites = 16 pairs = one MFMA tile; a column of the march is
+// (cross-section, segment).  The LDS image of a halo row of a segment holds the 17 slots 16 h .. 16 h + 16 (mod L3 / 2) of both
+// parity blocks of the pair tensor's row, hi and lo: [hi | lo][even | odd][16 slots] (1 KiB, one DMA piece) + the 17th slots
+// (64 B, a second, 4-lane piece).  SEGM = false is the L3 = 32 case: one segment is the whole periodic row, slot 16 IS slot 0,
+// no second piece (the taps wrap by address).
+template <bool SEGM>
+struct Geo {
+  static constexpr int RBL = SEGM ? 1088 : 1024;            // bytes of a row image in LDS
+  static constexpr int PLROWS = 16;                         // halo rows of a plane: (z0, z1) in {-1..2}^2, row index 4*hz0 + hz1
+  static constexpr int PLANE = PLROWS * RBL;                // 16 / 17 KiB
+  static constexpr int NSLOT = 8;                           // ring: 4 planes being read + 4 ahead
+  static constexpr int RING = NSLOT * PLANE;                // 128 / 136 KiB
+  static constexpr int XBUF = 4 * 2 * 64 * 16;              // partial-sum exchange: [wave pair][direction][lane] x 16 B, one of two buffers
+  static constexpr int LDS_BYTES = RING + 2 * XBUF;         // 147456 / 155648 <= 163840
+  static_assert(LDS_BYTES <= 160 * 1024, "ring + exchange must fit the CU's LDS");
+};
 constexpr int NSA = 14;                       // slices of the A waves (0..13); B waves: 14..26
 constexpr float kInvWScale = 1.0f / 1024.0f;  // the weights are packed scaled by 2^10 (normflow__amd/_hip.py: SPLIT16_WEIGHT_SCALE)
-static_assert(LDS_BYTES <= 160 * 1024, "ring + exchange must fit the CU's LDS");
 }  // namespace g2
 
 // tanh(v) for v = a * scale + bias given as (a, c1 = 2 log2(e) scale, c0 = 2 log2(e) bias): 1 - 2 / (1 + 2^(c1 a + c0)); five
@@ -57,8 +64,11 @@ __device__ __forceinline__ float tanh_affine(float a, float c1, float c0) {
   return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + t), 1.0f);
 }
 
+template <bool SEGM>
 __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
   using namespace g2;
+  typedef Geo<SEGM> G;
+  constexpr int RBL = G::RBL, PLANE = G::PLANE, NSLOT = G::NSLOT, RING = G::RING, XBUF = G::XBUF;
   extern __shared__ __align__(16) unsigned char smem_g2[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -72,7 +82,9 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
   // XCD: the 32 columns an XCD marches at the same time are neighbours and share their halo rows in its L2.
   const int n0 = A.L[0] >> 1, n1 = A.L[1] >> 1, ncol = n0 * n1;
   const int L2 = A.L[2], nstep = L2 >> 1;                       // steps per column; its ring entries are the planes -1 .. L2
-  const int total = int(A.nitems);                                // B * ncol columns (< 2^31: checked by the launcher)
+  const int L3 = A.L[3], HP = L3 >> 1, NSEG = (HP + 15) >> 4;    // sites / pairs of a row; segments per row (1 when !SEGM)
+  const int RB = L3 * 32, HB = L3 * 16, PB = L3 * 8;             // bytes of a row of the pair tensor / its hi block / a parity block
+  const int total = int(A.nitems);                                // B * ncol * NSEG columns (< 2^31: checked by the launcher)
   const int xcd = blockIdx.x & 7, jm = blockIdx.x >> 3;
   auto col_id = [&](int ci) { return (xcd + 8 * ci) * 32 + jm; };
   int ncols_my = 0;
@@ -81,8 +93,13 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
     if (first < total) ncols_my = (total - first + 255) / 256;
   }
   if (ncols_my == 0) return;
-  auto decode = [&](int ci, int &b, int &i0, int &i1) {
-    const int gc = col_id(ci);
+  auto decode = [&](int ci, int &b, int &i0, int &i1, int &hs) {
+    int gc = col_id(ci);
+    hs = 0;
+    if (SEGM) {                                // the segment is the fastest index: a row's segments run at the same time
+      hs = gc % NSEG;
+      gc /= NSEG;
+    }
     b = gc / ncol;
     const int c = gc - b * ncol;
     i0 = c / n1;
@@ -110,13 +127,19 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
   }
   const float kc1 = 2.885390081777927f * kInvWScale;
 
-  // ---- A-fragment addressing.  Lane (pair p, k-group g) reads tap g of its pair: site 2p + g - 1 (mod L3) -- parity block
-  // (g + 1) & 1, slot p + (g >> 1) (mod 16) of the row image (pair_row_offset).  The row of tile t (plane 2s + t of the step) at
-  // tap j2 of combo (j0, j1) is halo row (z0 + j0, z1 + j1) of ring plane t + j2.
-  const unsigned lane_a = unsigned((((g + 1) & 1) * PB) + (((p + (g >> 1)) & 15) * 16) + (((q >> 1) * 4 + (q & 1)) * RB));
-  // ---- DMA: wave w copies halo rows 2w and 2w + 1 of every plane; lane l brings bytes [16 l, 16 l + 16) of the row
+  // ---- A-fragment addressing.  Lane (pair p, k-group g) reads tap g of its pair q = 16 hs + p: site 2q + g - 1 -- parity block
+  // (g + 1) & 1, slot q + (g >> 1) of the pair tensor's row (pair_row_offset), i.e. LOCAL slot j = p + (g >> 1) of the segment's
+  // image: j < 16 in the main piece, j = 16 (lane p = 15 of taps 2, 3) its 17th slot -- or, when the segment is the whole
+  // periodic row, slot 0.  The row of tile t (plane 2s + t of the step) at tap j2 of combo (j0, j1) is halo row
+  // (z0 + j0, z1 + j1) of ring plane t + j2.
+  const int ja = p + (g >> 1), para = (g + 1) & 1;
+  const unsigned rowsel = unsigned(((q >> 1) * 4 + (q & 1)) * RBL);
+  const unsigned lane_a = rowsel + unsigned((SEGM && ja == 16) ? 1024 + para * 16 : para * 256 + (ja & 15) * 16);
+  const unsigned lane_al = lane_a + unsigned((SEGM && ja == 16) ? 32 : 512);       // its lo half
+  // ---- DMA: wave w copies halo rows 2w and 2w + 1 of every plane; lane l brings slot (16 hs + (l & 15)) mod HP of block l >> 4
+  // ([hi | lo][even | odd]) of the row; lanes 0..3 of a second piece bring the 17th slot of the four blocks
   const int hz0 = wave >> 1, hz1a = 2 * (wave & 1);
-  const unsigned lane_d = unsigned(lane * 16);
+  unsigned lane_d = unsigned(lane * 16), lane_d2 = 0;          // per-lane source offsets inside a row (per column when SEGM)
   const unsigned char *__restrict__ inb = static_cast<const unsigned char *>(A.in);
   const int64_t sampleB = A.V * 32;           // bytes of one sample's pair tensor
 
@@ -125,8 +148,8 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
   int ici = 0, ipl = -1, head = 0;
   const unsigned char *rowp[2] = {nullptr, nullptr};
   auto open_issue_column = [&]() {
-    int ib, ii0, ii1;
-    decode(ici, ib, ii0, ii1);
+    int ib, ii0, ii1, hs;
+    decode(ici, ib, ii0, ii1, hs);
     int x0 = 2 * ii0 + hz0 - 1;
     x0 = x0 < 0 ? x0 + A.L[0] : (x0 >= A.L[0] ? x0 - A.L[0] : x0);
 #pragma unroll
@@ -135,15 +158,30 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
       x1 = x1 < 0 ? x1 + A.L[1] : (x1 >= A.L[1] ? x1 - A.L[1] : x1);
       rowp[k] = inb + int64_t(ib) * sampleB + int64_t((x0 * A.L[1] + x1) * L2) * RB;
     }
+    if (SEGM) {
+      const int blk = lane >> 4;               // piece 1: block (hl = blk >> 1, parity = blk & 1), local slot lane & 15
+      int gs = 16 * hs + (lane & 15);
+      gs = gs >= HP ? gs - HP : gs;
+      lane_d = unsigned((blk >> 1) * HB + (blk & 1) * PB + gs * 16);
+      int g17 = 16 * hs + 16;                  // piece 2 (lanes 0..3): block = lane, the 17th slot
+      g17 = g17 >= HP ? g17 - HP : g17;
+      lane_d2 = unsigned(((lane >> 1) & 1) * HB + (lane & 1) * PB + g17 * 16);
+    }
   };
   open_issue_column();
-  const unsigned lds_rows = lds0 + unsigned((hz0 * 4 + hz1a) * RB);
-  // One piece = one halo row (1 KiB).  A wave brings rows (hz0, hz1a) and (hz0, hz1a + 1) of every plane: pieces k = 0, 1 of
-  // the entry under the cursor; the cursor moves on after the second.
+  const unsigned lds_rows = lds0 + unsigned((hz0 * 4 + hz1a) * RBL);
+  // One piece = one halo row image (1 KiB, + the 64-byte piece of 17th slots when SEGM).  A wave brings rows (hz0, hz1a) and
+  // (hz0, hz1a + 1) of every plane: pieces k = 0, 1 of the entry under the cursor; the cursor moves on after the second.
+  constexpr int PPP = SEGM ? 2 : 1;           // DMA instructions per piece
   auto issue_piece = [&](int k) {
     if (ici >= ncols_my) return false;
     const int x2 = ipl < 0 ? L2 - 1 : (ipl >= L2 ? 0 : ipl);
-    dma_row(rowp[k] + unsigned(x2) * unsigned(RB), lane_d, lds_rows + unsigned((head & (NSLOT - 1)) * PLANE + k * RB));
+    const unsigned char *src = rowp[k] + unsigned(x2) * unsigned(RB);
+    const unsigned dst = lds_rows + unsigned((head & (NSLOT - 1)) * PLANE + k * RBL);
+    dma_row(src, lane_d, dst);
+    if (SEGM) {
+      if (lane < 4) dma_row(src, lane_d2, dst + 1024u);
+    }
     if (k == 1) {
       ++head;
       if (++ipl > L2) {
@@ -165,24 +203,29 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
   const int te = isB ? 1 : 0;                 // the tile whose epilogue is mine (plane 2s + te of a step)
   unsigned char *__restrict__ outb = static_cast<unsigned char *>(A.out);
   unsigned char *ocol = nullptr;              // the current column's output row of this wave at plane te
+  unsigned lane_o = 0;                        // the epilogue's store: lane (p, g) holds channels 4 (g & 1) .. + 3 of site 2q + (g >> 1)
+  bool lane_ok = true;                        // my pair exists (a partial last segment has 8 of 16)
   auto open_column = [&](int ci) {
-    int b, i0, i1;
-    decode(ci, b, i0, i1);
+    int b, i0, i1, hs;
+    decode(ci, b, i0, i1, hs);
+    const int qq = 16 * hs + p;
+    lane_ok = qq < HP;
+    lane_o = unsigned(pair_row_offset(lane_ok ? 2 * qq + (g >> 1) : 0, L3) + (g & 1) * 8);
     ocol = outb + int64_t(b) * sampleB + int64_t(((2 * i0 + (q >> 1)) * A.L[1] + 2 * i1 + (q & 1)) * L2 + te) * RB;
   };
   open_column(0);
   int cci = 0, s = 0;                         // the column's index in my list, the step inside it
   int rbase = 0;                              // ring entry of plane 2s - 1 of the current column (mod 8 gives the slot)
   f32x4 prev = f32x4{0.f, 0.f, 0.f, 0.f};     // my partial sums of MY tile from the previous step (its epilogue is pending)
-  unsigned char *pout = nullptr;              // ... and the row it goes to
+  unsigned char *pout = nullptr;              // ... and the row it goes to (with the lane's offset and validity in THAT column)
+  unsigned plane_o = 0;
+  bool plane_ok = true;
   bool have_prev = false;
   int free_next = 0;                          // ring entries freed by the previous step (2, or 4 at a column end)
   const int nsteps_total = ncols_my * nstep;
   // exchange slots of this pair in a buffer: [0] A -> B (tile 1's partial sums of A), [1] B -> A (tile 0's of B)
   const unsigned xsend = unsigned(RING + (q * 2 + (isB ? 1 : 0)) * 1024 + lane * 16);
   const unsigned xrecv = unsigned(RING + (q * 2 + (isB ? 0 : 1)) * 1024 + lane * 16);
-  // the epilogue's store: lane (p, g) holds channels 4 (g & 1) .. + 3 of site 2p + (g >> 1)
-  const unsigned lane_o = unsigned(pair_row_offset(2 * p + (g >> 1), L3) + (g & 1) * 8);
 
 #if defined(NF_DIAG) && defined(NF_G2_TIMING)      // diagnostic build: cycle counters around the phases of a step
   unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
@@ -202,9 +245,11 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
       hi[r] = h0;
       lo[r] = static_cast<_Float16>(v - static_cast<float>(h0));
     }
-    unsigned char *d = pout + lane_o;
-    *reinterpret_cast<f16x4 *>(d) = hi;
-    *reinterpret_cast<f16x4 *>(d + HB) = lo;
+    if (plane_ok) {
+      unsigned char *d = pout + plane_o;
+      *reinterpret_cast<f16x4 *>(d) = hi;
+      *reinterpret_cast<f16x4 *>(d + HB) = lo;
+    }
   };
 
   for (int k = 0; k < nsteps_total; ++k) {
@@ -214,12 +259,12 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
     // issue.  Two entries = four pieces per wave; a column's first step has four entries: the extra two go out right here.
     int ndma = 0;
     if (!(NF_G2_ABL & 1) && free_next == 4) {
-      ndma += issue_entry() ? 2 : 0;
-      ndma += issue_entry() ? 2 : 0;
+      ndma += issue_entry() ? 2 * PPP : 0;
+      ndma += issue_entry() ? 2 * PPP : 0;
     }
     const bool refill = !(NF_G2_ABL & 1) && free_next >= 2;
     auto dma_slot = [&](int i) {               // slot i of 4: piece i & 1 of the entry under the cursor
-      if (refill && issue_piece(i & 1)) ++ndma;
+      if (refill && issue_piece(i & 1)) ndma += PPP;
     };
     NF_G2TICK(0)      // step head
     // (2) the epilogue of MY tile of the previous step: B waves run it now, A waves after their MFMAs -- so that right behind
@@ -230,9 +275,13 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
     // (3) my share of the 27 slices, for both tiles
     f32x4 am[2], ac[2];                        // per tile: hi*hi sums, and the two correction products
     am[0] = am[1] = ac[0] = ac[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    unsigned rowa[4];                          // LDS offset of this lane's fragment in ring plane (rbase + i), combo (0, 0)
+    unsigned rowa[4], rowl[4];                 // LDS offset of this lane's fragment (hi, lo) in ring plane (rbase + i), combo (0, 0)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rowa[i] = unsigned(((rbase + i) & (NSLOT - 1)) * PLANE) + lane_a;
+    for (int i = 0; i < 4; ++i) {
+      const unsigned po = unsigned(((rbase + i) & (NSLOT - 1)) * PLANE);
+      rowa[i] = po + lane_a;
+      rowl[i] = po + lane_al;
+    }
     // rows I0 .. I1 of combo offset coff (tap j2 of tile t reads row t + j2)
     auto fetch = [&](f16x8 (&fh)[4], f16x8 (&fl)[4], int coff, int I0, int I1) {
 #pragma unroll
@@ -243,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
           asm volatile("" : "+v"(fh[i]), "+v"(fl[i]));
         } else {
           fh[i] = *reinterpret_cast<const f16x8 *>(smem_g2 + rowa[i] + coff);
-          fl[i] = *reinterpret_cast<const f16x8 *>(smem_g2 + rowa[i] + coff + HB);
+          fl[i] = *reinterpret_cast<const f16x8 *>(smem_g2 + rowl[i] + coff);
         }
       }
     };
@@ -272,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
         for (int t = 0; t < 2; ++t)
           if (j2 >= J0 && j2 <= J1) ac[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[base + j2], fl[t + j2], ac[t], 0, 0, 0);
     };
-    auto combo_off = [](int jj) { return ((jj / 3) * 4 + jj % 3) * RB; };      // halo row (j0, j1) relative to the pair's own
+    auto combo_off = [](int jj) { return ((jj / 3) * 4 + jj % 3) * RBL; };      // halo row (j0, j1) relative to the pair's own
     f16x8 fh0[4], fl0[4], fh1[4], fl1[4];
     // (sched_barrier: left alone the compiler sinks every fragment read next to its first use and exposes the LDS latency
     //  at each MFMA group; the reads of the next combo must issue BEFORE the current combo's MFMAs)
@@ -321,13 +370,17 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
     *reinterpret_cast<f32x4 *>(smem_g2 + (k & 1) * XBUF + xsend) = isB ? am[0] : am[1];
     prev = isB ? am[1] : am[0];
     pout = ocol + unsigned(2 * s) * unsigned(RB);
+    plane_o = lane_o;
+    plane_ok = lane_ok;
     have_prev = true;
     // (5) the planes of the NEXT step were issued a full step ago or earlier: everything but this step's own DMAs (the
     // youngest operations: the epilogue's stores precede them) must have landed before the barrier.  A column's first step
     // reads four planes, the last two of which were issued during THIS step when this is a column's last step: then they
     // must land as well.
     const int allow = s + 1 == nstep ? 0 : ndma;
-    if (allow >= 8) wait_vm<8>();
+    if (allow >= 16) wait_vm<16>();
+    else if (allow >= 12) wait_vm<12>();
+    else if (allow >= 8) wait_vm<8>();
     else if (allow >= 6) wait_vm<6>();
     else if (allow >= 4) wait_vm<4>();
     else if (allow >= 2) wait_vm<2>();
@@ -365,7 +418,7 @@ extern "C" int nf_conv_split16_supported(const int32_t *lattice, const int32_t *
   if (act != kActTanh && act != kActSigmoid) return 0;                    // the OUTPUT must be fp16-safe as well
   for (int mu = 0; mu < 4; ++mu)
     if (ksize[mu] != 3) return 0;
-  if (lattice[3] != g2::L3) return 0;
+  if (lattice[3] < 32 || (lattice[3] & 15)) return 0;                     // whole or half segments of 32 sites
   for (int mu = 0; mu < 3; ++mu)
     if (lattice[mu] < 2 || (lattice[mu] & 1)) return 0;
   return 1;
@@ -376,7 +429,7 @@ extern "C" int nf_conv_fwd_split16(const void *in16, const void *wsplit, const v
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   NF_REQUIRE(in16 && wsplit && out16 && lattice, "nf_conv_fwd_split16: NULL pointer");
   const int32_t k3[4] = {3, 3, 3, 3};
-  NF_REQUIRE(nf_conv_split16_supported(lattice, k3, 8, 8, act), "nf_conv_fwd_split16: layer not supported (needs a 32-site fastest axis, even other extents, tanh / sigmoid)");
+  NF_REQUIRE(nf_conv_split16_supported(lattice, k3, 8, 8, act), "nf_conv_fwd_split16: layer not supported (needs a fastest axis of 32 + 16 n sites, even other extents, tanh / sigmoid)");
   NF_REQUIRE(B >= 0 && B <= 65535, "nf_conv_fwd_split16: batch outside [0, 65535]");
   NF_REQUIRE(in16 != out16, "nf_conv_fwd_split16: in place is not possible (a layer reads its neighbours' inputs)");
   if (B == 0) return NF_OK;
@@ -388,14 +441,21 @@ extern "C" int nf_conv_fwd_split16(const void *in16, const void *wsplit, const v
     A.V *= lattice[mu];
   }
   A.cin = 8; A.cout = 8; A.act = act;
-  A.nitems = B * int64_t(lattice[0] / 2) * int64_t(lattice[1] / 2);      // columns
+  const bool segm = lattice[3] != 32;
+  A.nitems = B * int64_t(lattice[0] / 2) * int64_t(lattice[1] / 2) * int64_t(segm ? (lattice[3] / 2 + 15) / 16 : 1);      // columns (x segments)
   NF_REQUIRE(A.V * 32 < (int64_t(1) << 32), "nf_conv_fwd_split16: a sample's pair tensor must stay below 4 GiB");
   NF_REQUIRE(A.nitems < (int64_t(1) << 31) - 4096, "nf_conv_fwd_split16: batch x columns >= 2^31, split the batch");
   // one persistent workgroup per CU of an MI355X; workgroup (xcd = id & 7, j = id >> 3) takes member j of every 8th group of
   // 32 columns (on a part with fewer CUs the surplus workgroups simply queue: there is no inter-workgroup dependency)
   const int64_t grid = 256;
-  NF_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_g2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, g2::LDS_BYTES) == hipSuccess,
-             "nf_conv_fwd_split16: cannot reserve %d B of LDS", g2::LDS_BYTES);
-  hipLaunchKernelGGL(conv_g2_kernel, dim3(unsigned(grid)), dim3(512), g2::LDS_BYTES, stream, A);
+  if (segm) {
+    NF_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_g2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, g2::Geo<true>::LDS_BYTES) == hipSuccess,
+               "nf_conv_fwd_split16: cannot reserve %d B of LDS", g2::Geo<true>::LDS_BYTES);
+    hipLaunchKernelGGL(conv_g2_kernel<true>, dim3(unsigned(grid)), dim3(512), g2::Geo<true>::LDS_BYTES, stream, A);
+  } else {
+    NF_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_g2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, g2::Geo<false>::LDS_BYTES) == hipSuccess,
+               "nf_conv_fwd_split16: cannot reserve %d B of LDS", g2::Geo<false>::LDS_BYTES);
+    hipLaunchKernelGGL(conv_g2_kernel<false>, dim3(unsigned(grid)), dim3(512), g2::Geo<false>::LDS_BYTES, stream, A);
+  }
   return check_launch("conv split-fp16 hidden-layer kernel");
 }

@@ -6,7 +6,7 @@ import numpy as np, torch
 from normflow__amd import _hip
 from oracle import nf_oracle as O
 DEV = torch.device("cuda", 0)
-for shape, B, xs in (((2, 2, 2, 32), 1, 1.0), ((2, 4, 4, 32), 2, 1.0), ((4, 2, 6, 32), 3, 30.0), ((4, 4, 8, 32), 9, 1e-3), ((8, 8, 8, 32), 3, 1.0), ((16, 16, 16, 32), 2, 1.0)):
+for shape, B, xs in (((2, 2, 2, 32), 1, 1.0), ((2, 4, 4, 32), 2, 1.0), ((4, 2, 6, 32), 3, 30.0), ((4, 4, 8, 32), 9, 1e-3), ((8, 8, 8, 32), 3, 1.0), ((16, 16, 16, 32), 2, 1.0), ((2, 2, 4, 48), 2, 1.0), ((4, 4, 4, 64), 3, 1.0), ((4, 2, 6, 48), 5, 1.0), ((2, 2, 2, 96), 1, 1.0)):
     g = torch.Generator(device='cpu').manual_seed(5)
     x = xs * torch.randn((B, 1) + shape, generator=g, dtype=torch.float64, device='cpu')
     w = 0.3 * torch.randn((8, 1, 3, 3, 3, 3), generator=g, dtype=torch.float64, device='cpu') / max(1.0, xs)

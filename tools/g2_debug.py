@@ -6,7 +6,7 @@ import numpy as np, torch
 from normflow__amd import _hip
 from oracle import nf_oracle as O
 DEV = torch.device("cuda", 0)
-for shape, B in (((2, 2, 2, 32), 1), ((2, 2, 4, 32), 1), ((4, 2, 6, 32), 3), ((4, 4, 8, 32), 9)):
+for shape, B in (((2, 2, 2, 32), 1), ((2, 2, 4, 32), 1), ((4, 2, 6, 32), 3), ((4, 4, 8, 32), 9), ((2, 2, 4, 48), 2), ((4, 4, 4, 64), 3), ((4, 2, 6, 48), 5), ((2, 2, 2, 96), 1), ((8, 8, 8, 48), 2)):
     g = torch.Generator(device='cpu').manual_seed(5)
     h = torch.tanh(torch.randn((B, 8) + shape, generator=g, dtype=torch.float64, device='cpu'))
     w = 0.2 * torch.randn((8, 8, 3, 3, 3, 3), generator=g, dtype=torch.float64, device='cpu')
