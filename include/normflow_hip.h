@@ -233,7 +233,8 @@ int nf_conv_fwd(const void *in, const void *wfrag, const void *bias, void *out, 
  *       lane = 16*g + n holds, for column 16*tile + n, the 8 input channels of kernel row 4i + g;
  *       hi = fp16(1024 w), lo = fp16(1024 w - hi) (the factor 2^10 keeps the lo parts of typical weights out of
  *       fp16's subnormal range; the kernel scales the accumulators back).  Needs max|w| < 29.
- * `fused`: bit 0 = the layer is the fused last layer (nf_conv_rqs), bit 1 = NF_CONV_UNIT_INPUT will be passed.
+ * `fused`: bit 0 = the layer is the fused last layer (nf_conv_rqs), bit 1 = NF_CONV_UNIT_INPUT will be passed, bit 2 =
+ * NF_CONV_SPLIT16_INPUT will be passed (the split-fp16 kernel takes fastest axes other than 32 sites only from a pair tensor).
  * Returns the code, or -1 for invalid arguments. */
 enum { NF_WLAYOUT_FRAGMENT = 0, NF_WLAYOUT_ROWPACK = 1, NF_WLAYOUT_SPLIT16 = 2 };
 int nf_conv_weight_layout(const int32_t *lattice, const int32_t *ksize, int cin, int cout, int compact,
@@ -244,7 +245,7 @@ int nf_conv_weight_layout(const int32_t *lattice, const int32_t *ksize, int cin,
  *   in16, out16: (B, V, 16) halfs; wsplit: [kernel row (27)][hi|lo][64 lanes][8] halfs -- lane 16*g + n holds, for column
  *   n = 8*shift + co, the 8 input channels of tap (g - shift) of that kernel row (zero outside 0..2), scaled by 2^10
  *   and split as in NF_WLAYOUT_SPLIT16; bias (8) fp32 or NULL; act must keep |out| <= 1 (tanh, logistic).
- *   nf_conv_split16_supported: 3^4 kernel, 8 -> 8 channels, 32-site fastest axis, even other extents. */
+ *   nf_conv_split16_supported: 3^4 kernel, 8 -> 8 channels, a fastest axis of 32 + 16 n sites, even other extents. */
 int nf_conv_split16_supported(const int32_t *lattice, const int32_t *ksize, int cin, int cout, int act);
 /* The FIRST ConvAct layer (1 -> 8 channels, 3^4 kernel, tanh / logistic) in front of the two entry points above (nf_conv_c.hip):
  * fp32 field in, fp16 pair tensor out, every fp32 product as three fp16 matrix-core products (x = x_hi + x_lo, |x| below the
@@ -253,8 +254,8 @@ int nf_conv_split16_supported(const int32_t *lattice, const int32_t *ksize, int 
  *   wsplit: [K slice (4)][hi|lo][64 lanes][8] halfs: K index = 4 r + t, r = kernel row (j0, j1, j2) row-major (27, padded to
  *   32 with zeros), t = tap of the site pair (sites 2p-1 .. 2p+2); lane 16*g + n (column n = 8*shift + co) holds rows
  *   8*slice + 2*g + h (h = 0, 1) as values 4*h + t = W[co][r][t - shift] (zero outside 0..2), scaled by 2^10 and split as
- *   in NF_WLAYOUT_SPLIT16.  nf_conv_first_split16_supported: 8 output channels, 3^4 kernel, 32-site fastest axis, even
- *   other extents. */
+ *   in NF_WLAYOUT_SPLIT16.  nf_conv_first_split16_supported: 8 output channels, 3^4 kernel, a fastest axis of 32 + 16 n
+ *   sites, even other extents. */
 int nf_conv_first_split16_supported(const int32_t *lattice, const int32_t *ksize, int cout, int act);
 int nf_conv_first_split16(const void *in, const void *wsplit, const void *bias, void *out16, int64_t B,
                           const int32_t *lattice, int act, void *stream);
@@ -275,7 +276,8 @@ int nf_conv_last_path(void);
  *   in (B, cin, V) hidden activations; wfrag/bias as nf_conv_fwd with cout = 3m-2;
  *   x_active, y (B, V); log0, logj (B); inverse != 0 applies the inverse map.
  *   flags: NF_CONV_UNIT_INPUT = the caller guarantees |in| <= 1 (hidden activations that are tanh / sigmoid
- *   outputs): eligible layers (8 -> 46 channels, 3^4 kernel, 32-site fastest axis) then run the split-fp16 kernel
+ *   outputs): eligible layers (8 -> 46 channels, 3^4 kernel, a fastest axis of 32 sites -- or, fed by a pair tensor, 32 + 16 n --, even
+ *   other extents) then run the split-fp16 kernel
  *   (nf_conv_h.hip): every fp32 product as three fp16 matrix-core products with fp32 accumulation, ~1.7x the
  *   rounding error of an fp32 chain, well inside the 1e-5 budget; the weights must then be packed in
  *   NF_WLAYOUT_SPLIT16 (nf_conv_weight_layout with `fused` = 1 | 2 says which layout a layer wants).

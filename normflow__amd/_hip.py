@@ -811,7 +811,7 @@ def conv_rqs(h, weight, bias, x_active, log0, parity, opts, inverse, unit_input=
         if not flags or h.dtype != torch.float16 or tuple(h.shape) != (B, V, 16):
             raise NormflowHipError("split-fp16 hidden activations need unit_input and a (B, V, 16) half tensor")
         flags |= 2                                                           # NF_CONV_SPLIT16_INPUT
-    wfrag = conv_weight_for_layer(weight.detach(), lat4, k4, cin, weight.shape[0], True, 1 | ((flags & 1) << 1), NF_F32)
+    wfrag = conv_weight_for_layer(weight.detach(), lat4, k4, cin, weight.shape[0], True, 1 | ((flags & 1) << 1) | ((flags & 2) << 1), NF_F32)
     bias = None if bias is None else bias.detach().contiguous()
     if out is None:
         y = torch.empty_like(x_active)

@@ -608,31 +608,41 @@ static int run_conv_t(const void *in, const void *wfrag, const void *bias, void 
     A.xact = fz->xact; A.yout = fz->yout; A.partial = fz->partial; A.P = fz->P;
     A.field16 = (fz->flags & NF_CONV_FIELD_F16) ? 1 : 0;
     NF_REQUIRE(A.nt_total <= 3, "nf_conv_rqs: at most 48 logit channels can be fused");
+  }
+  g_last_path = 0;
+  // the split-fp16 fused kernel (nf_conv_h.hip) first: it has its own box (2 x 2 x 2 rows x a 32-site segment), hence its own
+  // number of log-det partials per sample
+  if (fz && (fz->flags & NF_CONV_UNIT_INPUT)) {
+    if constexpr (sizeof(T) == 4) {
+      if (fz->flags & NF_CONV_SPLIT16_INPUT) A.in_split16 = 1;
+      int64_t nbh = 0;
+      if (conv_h_eligible(A, fuse, &nbh)) {
+        if (g_dry_layout) { *g_dry_layout = NF_WLAYOUT_SPLIT16; return NF_OK; }
+        const size_t need = size_t(B) * size_t(nbh) * sizeof(double);
+        if (fz->partial == nullptr || fz->partial_bytes < need) {
+          set_error("nf_conv_rqs: workspace %zu B < %zu B needed", fz->partial_bytes, need);
+          return NF_EWORKSPACE;
+        }
+        *fz->blocks_out = nbh;
+        const int pr = launch_conv_h(A, B, fuse, stream, false);
+        if (pr == -2) { set_error("nf_conv_rqs: batch x boxes >= 2^31 work items, split the batch"); return NF_EINVAL; }
+        if (pr != 1) { set_error("nf_conv_rqs: could not launch the split-fp16 kernel"); return NF_ELAUNCH; }
+        g_last_path = 3;
+        return check_launch("conv split-fp16 kernel");
+      }
+    }
+  }
+  if (fz && (fz->flags & NF_CONV_SPLIT16_INPUT) && !g_dry_layout) {
+    set_error("nf_conv_rqs: split-fp16 input but the layer is not eligible for the split-fp16 kernel");
+    return NF_EINVAL;
+  }
+  if (fz) {
     const size_t need = size_t(B) * size_t(nblocks) * sizeof(double);
     if (fz->partial == nullptr || fz->partial_bytes < need) {
       set_error("nf_conv_rqs: workspace %zu B < %zu B needed", fz->partial_bytes, need);
       return NF_EWORKSPACE;
     }
     *fz->blocks_out = nblocks;
-  }
-  g_last_path = 0;
-  if (fz && (fz->flags & NF_CONV_SPLIT16_INPUT))
-    NF_REQUIRE((fz->flags & NF_CONV_UNIT_INPUT) && sizeof(T) == 4 && MT == 2, "nf_conv_rqs: split-fp16 input without the split-fp16 kernel");
-  if (fz && (fz->flags & NF_CONV_UNIT_INPUT)) {
-    if constexpr (sizeof(T) == 4) {
-      if (MT == 2) {     // split-fp16 products, weight-stationary (nf_conv_h.hip)
-        if (fz->flags & NF_CONV_SPLIT16_INPUT) A.in_split16 = 1;     // carried to the kernel in a spare bit
-        const int pr = launch_conv_h(A, B, nblocks, fuse, stream, g_dry_layout != nullptr);
-        if (pr == -2) { set_error("nf_conv_rqs: batch x boxes >= 2^31 work items, split the batch"); return NF_EINVAL; }
-        if (pr < 0) { set_error("nf_conv_rqs: could not launch the split-fp16 kernel"); return NF_ELAUNCH; }
-        if (pr == 1) {
-          if (g_dry_layout) { *g_dry_layout = NF_WLAYOUT_SPLIT16; return NF_OK; }
-          g_last_path = 3;
-          return check_launch("conv split-fp16 kernel");
-        }
-        NF_REQUIRE(!(fz->flags & NF_CONV_SPLIT16_INPUT), "nf_conv_rqs: split-fp16 input but the layer is not eligible for the split-fp16 kernel");
-      }
-    }
   }
   if (g_dry_layout) {                  // nf_conv_weight_layout: report which kernel (hence weight layout) this layer gets
     int pr = 0;
@@ -748,7 +758,7 @@ extern "C" int nf_conv_weight_layout(const int32_t *lattice, const int32_t *ksiz
   int64_t blocks = 0;
   FuseInfo fz{};
   fz.mode = 1;
-  fz.flags = (fused & 2) ? NF_CONV_UNIT_INPUT : 0;
+  fz.flags = ((fused & 2) ? NF_CONV_UNIT_INPUT : 0) | ((fused & 4) ? NF_CONV_SPLIT16_INPUT : 0);
   fz.P.m = (cout + 2) / 3;                                  // knots_len of the fused spline (planning only)
   fz.partial = reinterpret_cast<double *>(uintptr_t(8));
   fz.partial_bytes = ~size_t(0);

@@ -400,7 +400,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, const int (&o)[
 }
 
 // nf_conv_pipe.hip: 1 = launched (dry: would launch), 0 = layer not eligible (use the one-box kernel), < 0 = error
-int launch_conv_h(const ConvArgs &A0, int64_t B, int64_t nboxes, int fuse, hipStream_t stream, bool dry);
+int conv_h_eligible(const ConvArgs &A, int fuse, int64_t *nboxes);
+int launch_conv_h(const ConvArgs &A0, int64_t B, int fuse, hipStream_t stream, bool dry);
 int launch_conv_c1(const ConvArgs &A0, int MT, int64_t B, int64_t nboxes, hipStream_t stream);
 int launch_conv_pipe(const ConvArgs &A0, int64_t B, int64_t nboxes, int fuse, hipStream_t stream, bool dry);
 

@@ -33,16 +33,21 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace h {
 constexpr int H0 = 4, H1 = 4, H2 = 4;                     // halo rows of a 2x2x2x32 box under a 3^4 kernel; the box spans the fastest axis
-constexpr int L3 = 32;                                    // (periodic): its two halo sites are the row's own end sites -- by address, not by copy
+constexpr int SEGW = 32;                                  // sites of a SEGMENT of the fastest axis = 16 pairs = one site tile per box row.
+// A box is 2 x 2 x 2 lattice rows x one segment.  SEGM = false: the segment is the whole periodic row (L3 = 32): its taps wrap by
+// address (slot index mod 16), no halo sites, no periodic copies.  SEGM = true (L3 = 48, 64, ...): a row image holds the 17
+// slots 16 h .. 16 h + 16 (mod L3 / 2) of the four blocks of the pair tensor's row.
 constexpr int NROW = H0 * H1 * H2;                        // 64 halo rows: one per lane of the loader wave
-// The LDS image of an item is the row-major pair layout itself (pair_row_offset, nf_conv_core.h): 64 halo rows of 1 KiB =
-// [hi | lo][even sites | odd sites][16 slots x 16 B]; the mover fills it by LDS-DMA, one row (1 KiB, contiguous in the pair
-// tensor) per wave-instruction -- no staging registers and no ds_write on the way.  The 16 lanes of a k-group of an A fragment
-// (v_mfma_f32_16x16x32_f16: k-group g = the 8 channels of ONE tap) read sites x3 = 2p + c - 1 mod 32 of one parity, i.e. the 16
-// slots of a parity block, rotated: 256 contiguous bytes, no bank conflict.  (In plain site order the same read strides 32
-// bytes: a 4-way conflict, measured 35 instead of ~18 cycles per MFMA.)
-constexpr int RB = L3 * 32, HB = L3 * 16;                 // bytes of a row image / of its hi block
-constexpr int ITEM = NROW * RB;                           // 64 KiB: one item's image (hi and lo)
+// The LDS image of an item is rows of the pair layout (pair_row_offset, nf_conv_core.h): 64 halo rows of
+// [hi | lo][even sites | odd sites][16 slots x 16 B] (1 KiB, one LDS-DMA piece = one wave-instruction) + when SEGM the four
+// 17th slots (64 B, a second 4-lane piece) -- no staging registers and no ds_write on the way.  The 16 lanes of a k-group of
+// an A fragment (v_mfma_f32_16x16x32_f16: k-group g = the 8 channels of ONE tap) read 16 consecutive slots of one parity
+// block (rotated, or shifted by one into the 17th): 256 contiguous bytes, no bank conflict.
+template <bool SEGM>
+struct Img {
+  static constexpr int RBL = SEGM ? 1088 : 1024;           // bytes of a row image
+  static constexpr int ITEM = NROW * RBL;                  // 64 / 68 KiB: one item's image (hi and lo)
+};
 __host__ __device__ constexpr int rowidx(int r) { return ((r / 9) * H1 + (r / 3) % 3) * H2 + r % 3; }   // kernel row -> halo row step
 // K slices of 32 = (4 kernel rows) x (8 channels) at ONE tap j3 of the fastest axis: slice sl = 7*j3 + i holds kernel
 // rows 4i .. 4i+3 (row 27 is padding: zero weights).  Same j3 for the four k-groups => same parity sub-image.
@@ -53,9 +58,9 @@ constexpr int C = 46, M = 16;
 constexpr int PTS = UNITS + 4;                            // row stride of the logit scratch in floats: +4 spreads the 16 channels a
                                                           // wave writes at once over the banks (stride 128 put them all on one)
 constexpr int PT = C * PTS * 4;                           // bytes of the logit scratch
-constexpr int LDS_BYTES = 2 * ITEM + PT;
-static_assert(2 * PT <= ITEM, "two planes of partial sums must fit a consumed image");
-static_assert(LDS_BYTES <= 160 * 1024, "two image pairs and the logit scratch must fit the CU's LDS");
+template <bool SEGM> constexpr int lds_bytes() { return 2 * Img<SEGM>::ITEM + PT; }
+static_assert(2 * PT <= Img<false>::ITEM, "two planes of partial sums must fit a consumed image");
+static_assert(lds_bytes<true>() <= 160 * 1024, "two item images and the logit scratch must fit the CU's LDS");
 
 }  // namespace h
 
@@ -74,9 +79,12 @@ __device__ __forceinline__ void static_for(F &&f) {
   }
 }
 
-template <int FUSE>
+template <int FUSE, bool SEGM>
 __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   using namespace h;
+  constexpr int RBL = Img<SEGM>::RBL, ITEM = Img<SEGM>::ITEM;
+  const int L3 = A.L[3], HP = L3 >> 1;                    // sites / pairs of a lattice row (L3 = 32 when !SEGM)
+  const int HB = L3 * 16, PBK = L3 * 8;                   // bytes of the hi block / of a parity block of a row of the pair tensor
   extern __shared__ __align__(16) unsigned char smem_h[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -144,19 +152,23 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     // byte offset of this lane's A read = T[site tile] + RG[i]: T places the lane's site (box row mt: z0 = mt>>2,
     // z1 = (mt>>1)&1, z2 = mt&1; halo index 2p + parity + j3) in its parity sub-image, RG adds the halo rows of kernel
     // row 4i + g.  Box extents are even, so the parity of a box row does not depend on the box.
-    int TP[2], RG[7];        // T[mt] = TP[(z0 + z1 + z2) & 1] + r0(mt) * RB, the second term a compile-time offset
+    int TP[2], TL[2], RG[7];  // hi / lo offsets of this lane's slot in a row image, by parity of the box row; halo rows of the slices
     {
       const int p = lane & 15;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const int x3 = (2 * p + ((A.parity + e) & 1) + W - 1) & (L3 - 1);      // tap W of active site p, wrapped
-        TP[e] = pair_row_offset(x3, L3);
+        // tap W of the active site 2p + a of pair p (a = (parity + e) & 1): site 2p + a + W - 1 = tap index gI = a + W of the pair:
+        // parity block (gI + 1) & 1, local slot p + (gI >> 1) (nf_conv_g.hip has the same four taps as its k-groups)
+        const int gI = ((A.parity + e) & 1) + W, ja = p + (gI >> 1), para = (gI + 1) & 1;
+        const bool x17 = SEGM && ja == 16;
+        TP[e] = x17 ? 1024 + para * 16 : para * 256 + (ja & 15) * 16;
+        TL[e] = TP[e] + (x17 ? 32 : 512);
       }
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
         const int r = 4 * i + g;
         const int rr = r < 27 ? r : 26;
-        RG[i] = (((rr / 9) * H1 + (rr / 3) % 3) * H2 + rr % 3) * RB;
+        RG[i] = (((rr / 9) * H1 + (rr / 3) % 3) * H2 + rr % 3) * RBL;
       }
     }
     // The three partial sums of a column tile: slot 0 (the wave's OWN column tile, w) stays in the accumulators; slots 1 and
@@ -192,6 +204,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     for (int m = 0; m < n_my; ++m) {
       const int ioff = (m & 1) * ITEM;
       const unsigned char *img[2] = {smem_h + ioff + TP[0], smem_h + ioff + TP[1]};
+      const unsigned char *iml[2] = {smem_h + ioff + TL[0], smem_h + ioff + TL[1]};
       auto fetch = [&](auto QC) {
         constexpr int qs = decltype(QC)::value;
         constexpr int i = qs >> 2, t0 = (qs & 3) * 2, q = qs & 1;
@@ -199,9 +212,9 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
         for (int t = 0; t < 2; ++t) {
           const int mt = t0 + t;
           const int z0 = mt >> 2, z1 = (mt >> 1) & 1, z2 = mt & 1;
-          const unsigned char *src = img[(z0 + z1 + z2) & 1] + RG[i] + ((z0 * H1 + z1) * H2 + z2) * RB;
-          fa[q][t] = *reinterpret_cast<const f16x8 *>(src);
-          fl[q][t] = *reinterpret_cast<const f16x8 *>(src + HB);
+          const int ro = RG[i] + ((z0 * H1 + z1) * H2 + z2) * RBL;
+          fa[q][t] = *reinterpret_cast<const f16x8 *>(img[(z0 + z1 + z2) & 1] + ro);
+          fl[q][t] = *reinterpret_cast<const f16x8 *>(iml[(z0 + z1 + z2) & 1] + ro);
         }
       };
       auto mult = [&](auto QC) {
@@ -297,15 +310,15 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   const int rs = lane >> 5, xs = lane & 31;
   const bool pre = A.in_split16 != 0;       // input already split (flag carried in the high bits of dbg)
   auto put = [&](unsigned char *imgH, int row, int x3, const f16x8 &hi, const f16x8 &lo) {
-    const int d = row * RB + pair_row_offset(x3, L3);
+    const int d = row * RBL + pair_row_offset(x3, SEGW);         // (whole-row segments only: the image row IS the pair row)
     *reinterpret_cast<f16x8 *>(imgH + d) = hi;
-    *reinterpret_cast<f16x8 *>(imgH + HB + d) = lo;
+    *reinterpret_cast<f16x8 *>(imgH + 512 + d) = lo;
   };
   auto put3 = [&](unsigned char *imgH, int row, const f16x8 &hi, const f16x8 &lo) { put(imgH, row, xs, hi, lo); };
   auto stage = [&](int b, const int (&o)[4], unsigned char *imgH) {
     const int myoff = row_offsets(o);
     if (pre) {
-      const unsigned char *__restrict__ src = static_cast<const unsigned char *>(A.in) + int64_t(b) * A.V * 32 + pair_row_offset(xs, L3);
+      const unsigned char *__restrict__ src = static_cast<const unsigned char *>(A.in) + int64_t(b) * A.V * 32 + pair_row_offset(xs, SEGW);
       f16x8 h0[PB], l0[PB], h1[PB], l1[PB];
       auto issue = [&](f16x8 (&h)[PB], f16x8 (&l)[PB], int p0) {
 #pragma unroll
@@ -314,7 +327,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
           const int ob = __builtin_amdgcn_readlane(myoff, 2 * (p0 + j) + 1);
           const unsigned char *q = src + int64_t(rs ? ob : oa) * 32;
           h[j] = *reinterpret_cast<const f16x8 *>(q);
-          l[j] = *reinterpret_cast<const f16x8 *>(q + L3 * 16);
+          l[j] = *reinterpret_cast<const f16x8 *>(q + 512);
         }
       };
       auto commit = [&](const f16x8 (&h)[PB], const f16x8 (&l)[PB], int p0) {
@@ -365,16 +378,21 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       commit(v1, p0 + PB);
     }
   };
-  auto pair_of = [&](int b, const int (&o)[4], int pass) {
+  auto pair_of = [&](int b, const int (&o)[4], int pass, bool &ok) {
     const int u = pass * 64 + lane;
-    const int mt = u >> 4, p3 = u & 15;
+    const int mt = u >> 4, p3 = (u & 15) + (o[3] >> 1);          // pair of the row: 16 hs + p
+    ok = p3 < HP;                                                 // (a partial last segment has 8 of 16)
     const int x0 = o[0] + (mt >> 2), x1 = o[1] + ((mt >> 1) & 1), x2 = o[2] + (mt & 1);
-    return int64_t(b) * (A.V / 2) + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * (A.L[3] / 2) + p3;
+    return int64_t(b) * (A.V / 2) + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * HP + (ok ? p3 : 0);
   };
   float2 xpre[2] = {{0.f, 0.f}, {0.f, 0.f}};     // the x pairs of the item whose logits are (about to be) in pt
   auto prefetch_x = [&](int b, const int (&o)[4]) {
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) xpre[pass] = load_field_pair(A, pair_of(b, o, pass));
+    for (int pass = 0; pass < 2; ++pass) {
+      bool ok;
+      const int64_t pr = pair_of(b, o, pass, ok);
+      xpre[pass] = load_field_pair(A, pr);
+    }
   };
   auto epilogue = [&](int b, const int (&o)[4], int64_t pidx) {
     const lds_f *ptl = (const lds_f *)(smem_h + 2 * ITEM);
@@ -384,7 +402,8 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       const int u = pass * 64 + lane;
       const int mt = u >> 4;
       const int offp = (A.parity + o[0] + (mt >> 2) + o[1] + ((mt >> 1) & 1) + o[2] + (mt & 1)) & 1;
-      const int64_t pair = pair_of(b, o, pass);
+      bool pok;
+      const int64_t pair = pair_of(b, o, pass, pok);
       const float2 xv = xpre[pass];
       RegCol<float, C> a;
 #pragma unroll
@@ -394,8 +413,10 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       float2 ov;
       ov.x = offp ? 0.f : val;
       ov.y = offp ? val : 0.f;
-      store_field_pair(A, pair, ov);
-      lacc += double(logd);
+      if (pok) {
+        store_field_pair(A, pair, ov);
+        lacc += double(logd);
+      }
     }
     const double tot = wave_sum(lacc);
     if (lane == 0) A.partial[pidx] = tot;
@@ -404,7 +425,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   int pb = 0, po[4] = {0, 0, 0, 0};            // the item whose logits sit in pt
   int cb, co4[4];
   decode(vb, cb, co4);
-  stage(cb, co4, smem_h);
+  if (!pre) stage(cb, co4, smem_h);            // (pre-split input: by LDS-DMA below, once its helpers exist)
   // Pre-split input (the pipeline's path): the next item's image is brought in by LDS-DMA, one halo row = one 1 KiB piece =
   // one wave-instruction (the pair tensor's rows ARE the image rows): no staging registers, no ds_write -- the mover's 128
   // 16-byte LDS stores per item used to take ~13 % of the kernel from the compute waves' fragment reads.
@@ -412,25 +433,45 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   const unsigned lane16 = unsigned(lane * 16);
   int dma_off = 0;                              // lane l: site offset of halo row l of the item being brought in
   const unsigned char *dma_src = nullptr;
+  unsigned lane_d = lane16, lane_d2 = 0;         // per-lane source offsets inside a row of the pair tensor (per item when SEGM)
   auto dma_open = [&](int b, const int (&o)[4]) {
     dma_off = row_offsets(o);
     dma_src = static_cast<const unsigned char *>(A.in) + int64_t(b) * A.V * 32;
+    if (SEGM) {
+      const int hs16 = o[3] >> 1;                // first pair of the segment = 16 hs
+      const int blk = lane >> 4;                 // piece 1: block (hl = blk >> 1, parity = blk & 1), local slot lane & 15
+      int gs = hs16 + (lane & 15);
+      gs = gs >= HP ? gs - HP : gs;
+      lane_d = unsigned((blk >> 1) * HB + (blk & 1) * PBK + gs * 16);
+      int g17 = hs16 + 16;                       // piece 2 (lanes 0..3): block = lane, the 17th slot
+      g17 = g17 >= HP ? g17 - HP : g17;
+      lane_d2 = unsigned(((lane >> 1) & 1) * HB + (lane & 1) * PBK + g17 * 16);
+    }
   };
   auto dma_rows = [&](unsigned buf, auto R0, auto R1) {     // halo rows [R0, R1) -> image buffer at LDS byte address buf
     constexpr int r0 = decltype(R0)::value, r1 = decltype(R1)::value;
 #pragma unroll
     for (int i = r0; i < r1; ++i) {
       const unsigned ro = unsigned(__builtin_amdgcn_readlane(dma_off, i));
-      dma_row(dma_src + uint64_t(ro) * 32u, lane16, buf + unsigned(i * RB));
+      const unsigned char *src = dma_src + uint64_t(ro) * 32u;
+      dma_row(src, lane_d, buf + unsigned(i * RBL));
+      if (SEGM) {
+        if (lane < 4) dma_row(src, lane_d2, buf + unsigned(i * RBL + 1024));
+      }
     }
   };
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, NROW / 2> IH;
+  typedef std::integral_constant<int, NROW> IN;
+  if (pre) {                                    // image 0
+    dma_open(cb, co4);
+    dma_rows(lds0m, I0{}, IN{});
+    wait_vm<0>();
+  }
   int n1b = cb, n1o[4] = {co4[0], co4[1], co4[2], co4[3]};      // item m + 1
   if (n_my > 1) advance(n1b, n1o);
   prefetch_x(cb, co4);
   lds_barrier();                                // P: image 0 ready
-  typedef std::integral_constant<int, 0> I0;
-  typedef std::integral_constant<int, NROW / 2> IH;
-  typedef std::integral_constant<int, NROW> IN;
   for (int m = 0; m < n_my; ++m) {
     if (m > 0 && !NF_DBG(A, 128)) epilogue(pb, po, int64_t(vb) + int64_t(m - 1) * nb);     // dbg 128: timing ablation
     prefetch_x(cb, co4);                        // for the epilogue of item m, one iteration from now
@@ -460,18 +501,33 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   epilogue(pb, po, int64_t(vb) + int64_t(n_my - 1) * nb);
 }
 
-// 1 = launched (dry: would launch), 0 = not this kernel's layer, < 0 error.  A0 is nf_conv.hip's planned argument block.
-int launch_conv_h(const ConvArgs &A0, int64_t B, int64_t nboxes, int fuse, hipStream_t stream, bool dry) {
+// Is this fused layer the split-fp16 kernel's, and with how many boxes per sample?  (The kernel has its own box: 2 x 2 x 2
+// lattice rows x one 32-site segment of the fastest axis.)
+int conv_h_eligible(const ConvArgs &A, int fuse, int64_t *nboxes) {
   using namespace h;
   if (!option(NF_OPT_SPLIT16) || !fuse) return 0;
-  ConvArgs A = A0;
-  if (A.cin != 8 || A.cout != C || A.P.m != M || A.P.fx || A.P.fy || NF_DBG(A, 15) || NF_STAMPS(A)) return 0;   // (bit 0x10000 of dbg: input already split)
+  if (A.cin != 8 || A.cout != C || A.P.m != M || A.P.fx || A.P.fy || NF_DBG(A, 15) || NF_STAMPS(A)) return 0;
   for (int mu = 0; mu < 4; ++mu)
     if (A.k[mu] != 3) return 0;
-  if (A.box[0] != 2 || A.box[1] != 2 || A.box[2] != 2 || A.box[3] != 32 || A.L[3] != 32) return 0;
+  if (A.L[3] < 32 || (A.L[3] & 15)) return 0;                // whole or half segments
+  if (A.L[3] != 32 && !A.in_split16) return 0;               // fp32 planes are staged by the whole-row fallback only
   for (int mu = 0; mu < 3; ++mu)
-    if (A.L[mu] < 2 || (A.L[mu] & 1)) return 0;           // even extents: whole boxes, row parity independent of the box
+    if (A.L[mu] < 2 || (A.L[mu] & 1)) return 0;             // even extents: whole boxes, row parity independent of the box
+  if (nboxes) *nboxes = int64_t(A.L[0] / 2) * (A.L[1] / 2) * (A.L[2] / 2) * ((A.L[3] / 2 + 15) / 16);
+  return 1;
+}
+
+// 1 = launched (dry: would launch), 0 = not this kernel's layer, < 0 error.  A0 is nf_conv.hip's planned argument block.
+int launch_conv_h(const ConvArgs &A0, int64_t B, int fuse, hipStream_t stream, bool dry) {
+  using namespace h;
+  int64_t nboxes = 0;
+  if (!conv_h_eligible(A0, fuse, &nboxes)) return 0;
   if (dry) return 1;
+  ConvArgs A = A0;
+  const bool segm = A.L[3] != 32;
+  A.box[0] = A.box[1] = A.box[2] = 2; A.box[3] = SEGW;
+  for (int mu = 0; mu < 3; ++mu) A.nbox[mu] = A.L[mu] / 2;
+  A.nbox[3] = (A.L[3] / 2 + 15) / 16;
   A.nitems = B * nboxes;
   A.nboxes = int(nboxes);
   if (A.nitems >= (int64_t(1) << 31) - 4096) return -2;
@@ -486,15 +542,13 @@ int launch_conv_h(const ConvArgs &A0, int64_t B, int64_t nboxes, int fuse, hipSt
   int64_t grid = ncu;
   if (grid > A.nitems) grid = A.nitems;
   grid = (grid + 7) & ~int64_t(7);
-  if (fuse == 1) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_h_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -1;
-    hipLaunchKernelGGL((conv_h_kernel<1>), dim3(unsigned(grid)), dim3(256), LDS_BYTES, stream, A);
-  } else {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_h_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -1;
-    hipLaunchKernelGGL((conv_h_kernel<2>), dim3(unsigned(grid)), dim3(256), LDS_BYTES, stream, A);
-  }
-  return 1;
+  auto go = [&](auto kern, int lds) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -1;
+    hipLaunchKernelGGL(kern, dim3(unsigned(grid)), dim3(256), lds, stream, A);
+    return 1;
+  };
+  if (fuse == 1) return segm ? go(&conv_h_kernel<1, true>, lds_bytes<true>()) : go(&conv_h_kernel<1, false>, lds_bytes<false>());
+  return segm ? go(&conv_h_kernel<2, true>, lds_bytes<true>()) : go(&conv_h_kernel<2, false>, lds_bytes<false>());
 }
-
 
 }  // namespace nf

@@ -197,7 +197,7 @@ class ConvAct(torch.nn.Sequential):
         k4 = (C.c_int32 * 4)(*list(last.weight.shape[2:]))
         if not _hip._weights_fit_fp16(last.weight):
             return False
-        if lib.nf_conv_weight_layout(lat4, k4, last.weight.shape[1], last.weight.shape[0], 1, 3, _hip.NF_F32) != 2:
+        if lib.nf_conv_weight_layout(lat4, k4, last.weight.shape[1], last.weight.shape[0], 1, 7, _hip.NF_F32) != 2:      # fused | unit input | pair-tensor input
             return False
         kp = list(prev.weight.shape[2:])
         return bool(lib.nf_conv_two_site(8, 0, lat[-1], kp[-1])) and lat[-1] % 4 == 0

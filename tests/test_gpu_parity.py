@@ -1065,7 +1065,8 @@ def test_example_script_runs_with_package_defaults():
         assert a < 1e-8 and b < 1e-8
 
 
-@pytest.mark.parametrize("shape,B", [((4, 2, 6, 32), 100), ((2, 2, 2, 32), 7), ((8, 8, 8, 32), 3)])
+@pytest.mark.parametrize("shape,B", [((4, 2, 6, 32), 100), ((2, 2, 2, 32), 7), ((8, 8, 8, 32), 3), ((2, 2, 4, 48), 9), ((4, 4, 4, 64), 5),
+                                     ((4, 2, 2, 96), 3), ((8, 4, 4, 48), 4)])
 def test_split_fp16_fused_last_layer(shape, B):
     """nf_conv_h.hip: the fused last layer with every fp32 product as three fp16 matrix-core products (hidden
     activations are tanh outputs, so |h| <= 1).  Against (a) the fp32 kernels run separately (conv + coupling) and
@@ -1107,7 +1108,8 @@ def test_split_fp16_fused_last_layer(shape, B):
         assert rel(yf[:nb], yo) <= 1e-5 and rel(lf[:nb], lo) <= 1e-5
 
 
-@pytest.mark.parametrize("shape,B", [((4, 2, 6, 32), 40), ((2, 4, 8, 32), 45), ((2, 2, 4, 32), 300)])
+@pytest.mark.parametrize("shape,B", [((4, 2, 6, 32), 40), ((2, 4, 8, 32), 45), ((2, 2, 4, 32), 300), ((2, 2, 4, 48), 30), ((4, 4, 2, 64), 12),
+                                     ((2, 4, 6, 48), 10)])
 def test_split_fp16_hidden_layer_and_chain(shape, B):
     """conv_g_kernel (8 -> 8 hidden layer on fp16 (hi, lo) pairs in and out) against the fp64 definition, and the whole
     split chain of a ConvAct stack (first layer writes the pairs, hidden layer, fused last layer) against the fp32
