@@ -247,6 +247,16 @@ int nf_conv_weight_layout(const int32_t *lattice, const int32_t *ksize, int cin,
  *   and split as in NF_WLAYOUT_SPLIT16; bias (8) fp32 or NULL; act must keep |out| <= 1 (tanh, logistic).
  *   nf_conv_split16_supported: 3^4 kernel, 8 -> 8 channels, a fastest axis of 32 + 16 n sites, even other extents. */
 int nf_conv_split16_supported(const int32_t *lattice, const int32_t *ksize, int cin, int cout, int act);
+/* The LAST layer of an AffineCoupling_'s net (8 -> 2 channels: t, s) fused with the coupling (src/nn/scalar/couplings_.py:123-139),
+ * fed by a pair tensor: y = t + x e^{-|s|}, logj = log0 - sum|s| (inverse != 0: x = (y - t) e^{|s|}, + sum|s|) at the active
+ * site of every pair, 0 at the frozen one; the (B, 2, V/2) parameter tensor never exists in memory.  Same kernel as
+ * nf_conv_fwd_split16 with another epilogue.
+ *   wsplit: the hidden-layer fragment format of nf_conv_fwd_split16 packed from the (8, 8, 3,3,3,3) tensor whose output
+ *   channels 0, 1 are the layer's weights and 2..7 zero; bias (8) fp32 (entries 0, 1 used) or NULL; x_active, y (B, V) fp32 --
+ *   or IEEE half with flags = NF_CONV_FIELD_F16; log0 (B) or NULL, logj (B): fp32; workspace as nf_workspace_bytes(B, V). */
+int nf_conv_affine_split16(const void *in16, const void *wsplit, const void *bias, const void *x_active, const void *log0,
+                           void *y, void *logj, int64_t B, const int32_t *lattice, int active_parity, int inverse,
+                           int flags, void *workspace, size_t workspace_bytes, void *stream);
 /* The FIRST ConvAct layer (1 -> 8 channels, 3^4 kernel, tanh / logistic) in front of the two entry points above (nf_conv_c.hip):
  * fp32 field in, fp16 pair tensor out, every fp32 product as three fp16 matrix-core products (x = x_hi + x_lo, |x| below the
  * fp16 range: beyond 6.5e4 the outputs are NaN, never silently wrong).

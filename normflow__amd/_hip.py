@@ -71,6 +71,7 @@ PROTOTYPES = {
     "nf_conv_last_path": (_I, []),
     "nf_conv_split16_supported": (_I, [_P, _P, _I, _I, _I]),
     "nf_conv_fwd_split16": (_I, [_P, _P, _P, _P, _I64, _P, _I, _P]),
+    "nf_conv_affine_split16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _I, _I, _I, _P, _SZ, _P]),
     "nf_conv_first_split16_supported": (_I, [_P, _P, _I, _I]),
     "nf_conv_first_split16": (_I, [_P, _P, _P, _P, _I64, _P, _I, _P]),
     "nf_conv_weight_layout": (_I, [_P, _P, _I, _I, _I, _I, _I]),
@@ -784,6 +785,37 @@ def conv_layer(x, weight, bias, act=0, compact=False, parity=0):
         return ConvFn.apply(x, weight, bias, act, compact, parity)
     x = x.contiguous()
     return _conv_launch(x, weight.detach(), None if bias is None else bias.detach(), act, compact, parity)
+
+
+def conv_affine_split16(h16, weight, bias, x_active, log0, parity, inverse, lattice, out=None):
+    """Fused last layer of an affine coupling's net + the coupling (nf_conv_affine_split16); inference only.
+    h16: the (B, V, 16) fp16 pair tensor of hidden activations; weight (2, 8, 3, 3, 3, 3), bias (2) | None; x_active (B, V)
+    fp32 or half; returns (y (B, V), logJ (B) fp32 / the field's fp32-or-wider dtype)."""
+    _require_device(h16, weight, bias, x_active, log0)
+    lib = load()
+    B, V = x_active.shape
+    x_active = x_active.contiguous()
+    lat4 = (C.c_int32 * 4)(*lattice)
+    w8 = weight.new_zeros((8, 8, 3, 3, 3, 3), dtype=torch.float32)
+    w8[:2] = weight.detach().float()
+    wsp = pack_conv_weight_split16_two_site(w8)
+    b8 = torch.zeros(8, dtype=torch.float32, device=x_active.device)
+    if bias is not None:
+        b8[:2] = bias.detach().float()
+    field16 = x_active.dtype == torch.float16
+    if out is None:
+        y = torch.empty_like(x_active)
+        logj = torch.empty(B, dtype=torch.float32, device=x_active.device)
+    else:
+        y, logj = out
+    ws = _workspace(min(B, MAX_B), V, x_active.device)
+    for b0 in range(0, B, MAX_B):
+        b1 = min(B, b0 + MAX_B)
+        l0 = log0[b0:b1] if log0 is not None else None
+        _check(lib.nf_conv_affine_split16(_ptr(h16[b0:b1]), _ptr(wsp), _ptr(b8), _ptr(x_active[b0:b1]), _ptr(l0),
+                                          _ptr(y[b0:b1]), _ptr(logj[b0:b1]), b1 - b0, lat4, int(parity), int(inverse),
+                                          4 if field16 else 0, _ptr(ws), ws.numel(), _stream()), "nf_conv_affine_split16")
+    return y, logj
 
 
 def conv_rqs(h, weight, bias, x_active, log0, parity, opts, inverse, unit_input=False, lattice=None, out=None):

@@ -64,7 +64,11 @@ __device__ __forceinline__ float tanh_affine(float a, float c1, float c0) {
   return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + t), 1.0f);
 }
 
-template <bool SEGM>
+// EPI = 0: bias + activation -> the pair tensor (a hidden layer).  EPI = 1 / 2: the LAST layer of an affine coupling's net
+// (output channel 0 = t, 1 = s; the other six columns carry zero weights) fused with the coupling itself
+// (src/nn/scalar/couplings_.py:123-139): y = t + x e^{-|s|} (1) or x = (y - t) e^{|s|} (2) at the active site of every pair,
+// 0 at the frozen one, and the per-sample log-det partials -- the (B, 2, V/2) parameter tensor never exists in memory.
+template <bool SEGM, int EPI>
 __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
   using namespace g2;
   typedef Geo<SEGM> G;
@@ -205,11 +209,23 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
   unsigned char *ocol = nullptr;              // the current column's output row of this wave at plane te
   unsigned lane_o = 0;                        // the epilogue's store: lane (p, g) holds channels 4 (g & 1) .. + 3 of site 2q + (g >> 1)
   bool lane_ok = true;                        // my pair exists (a partial last segment has 8 of 16)
+  int64_t fcol = 0;                           // EPI > 0: pair index of this lane's pair in the column's row at plane te
+  int col_slot = 0;                           // EPI > 0: slot of this (column, wave) among the sample's log-det partials
   auto open_column = [&](int ci) {
     int b, i0, i1, hs;
     decode(ci, b, i0, i1, hs);
     const int qq = 16 * hs + p;
     lane_ok = qq < HP;
+    if (EPI > 0) {
+      const int x0 = 2 * i0 + (q >> 1), x1 = 2 * i1 + (q & 1);
+      // the active site of a pair of row (x0, x1, x2): site parity (A.parity + x0 + x1 + x2) & 1; planes 2s + te: x2 parity = te
+      const int a = (A.parity + x0 + x1 + te) & 1;
+      lane_ok = lane_ok && g == 2 * a;        // the lanes that hold channels 0..3 (t, s, -, -) of the ACTIVE site
+      fcol = ((int64_t(b) * A.L[0] + x0) * A.L[1] + x1) * int64_t(L2) * HP + int64_t(te) * HP + (qq < HP ? qq : 0);
+      const int per = ncol * NSEG;            // columns per sample
+      const int gc = col_id(ci);
+      col_slot = (gc - (gc / per) * per) * 8 + wave + (gc / per) * per * 8;      // sample-major: [sample][column][wave]
+    }
     lane_o = unsigned(pair_row_offset(lane_ok ? 2 * qq + (g >> 1) : 0, L3) + (g & 1) * 8);
     ocol = outb + int64_t(b) * sampleB + int64_t(((2 * i0 + (q >> 1)) * A.L[1] + 2 * i1 + (q & 1)) * L2 + te) * RB;
   };
@@ -220,6 +236,9 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
   unsigned char *pout = nullptr;              // ... and the row it goes to (with the lane's offset and validity in THAT column)
   unsigned plane_o = 0;
   bool plane_ok = true;
+  int64_t pfield = 0;                         // EPI > 0: pair index of the step whose epilogue is pending
+  int pslot = -1, aslot = -1;                 // ... its partial slot; the slot the running log-det sum belongs to
+  double lacc = 0.0;
   bool have_prev = false;
   int free_next = 0;                          // ring entries freed by the previous step (2, or 4 at a column end)
   const int nsteps_total = ncols_my * nstep;
@@ -233,22 +252,49 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
 #else
 #define NF_G2TICK(i)
 #endif
+  auto flush = [&]() {                        // EPI > 0: the finished column's log-det partial of this wave
+    const double tot = wave_sum(lacc);
+    if (lane == 0 && aslot >= 0) A.partial[aslot] = tot;
+    lacc = 0.0;
+  };
   auto epilogue = [&](int xbuf) {
-    // partner's partial sums of my tile + mine -> bias, activation -> (hi, lo) halves of this lane's 4 channels of its site
+    // partner's partial sums of my tile + mine
     const f32x4 pa = *reinterpret_cast<const f32x4 *>(smem_g2 + xbuf * XBUF + xrecv);
-    f16x4 hi, lo;
+    if constexpr (EPI == 0) {
+      // -> bias, activation -> (hi, lo) halves of this lane's 4 channels of its site
+      f16x4 hi, lo;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float a = prev[r] + pa[r];
-      const float v = A.act == kActTanh ? tanh_affine(a, kc1, kc0[r]) : activate(a * kInvWScale + bv4[r], kActSigmoid);
-      const _Float16 h0 = static_cast<_Float16>(v);
-      hi[r] = h0;
-      lo[r] = static_cast<_Float16>(v - static_cast<float>(h0));
-    }
-    if (plane_ok) {
-      unsigned char *d = pout + plane_o;
-      *reinterpret_cast<f16x4 *>(d) = hi;
-      *reinterpret_cast<f16x4 *>(d + HB) = lo;
+      for (int r = 0; r < 4; ++r) {
+        const float a = prev[r] + pa[r];
+        const float v = A.act == kActTanh ? tanh_affine(a, kc1, kc0[r]) : activate(a * kInvWScale + bv4[r], kActSigmoid);
+        const _Float16 h0 = static_cast<_Float16>(v);
+        hi[r] = h0;
+        lo[r] = static_cast<_Float16>(v - static_cast<float>(h0));
+      }
+      if (plane_ok) {
+        unsigned char *d = pout + plane_o;
+        *reinterpret_cast<f16x4 *>(d) = hi;
+        *reinterpret_cast<f16x4 *>(d + HB) = lo;
+      }
+    } else {
+      // -> (t, s) of the active site -> the affine map on the field, log-det -= / += |s|
+      if (pslot != aslot) {                   // (wave-uniform) a new column: hand the finished one's sum over
+        flush();
+        aslot = pslot;
+      }
+      if (plane_ok) {
+        const float t = (prev[0] + pa[0]) * kInvWScale + bv4[0];
+        const float sa = __builtin_fabsf((prev[1] + pa[1]) * kInvWScale + bv4[1]);
+        const float2 xv = load_field_pair(A, pfield);
+        const int a = g >> 1;                 // which site of the pair is the active one (this lane holds it)
+        const float v = a ? xv.y : xv.x;
+        const float val = EPI == 2 ? (v - t) * nf_exp(sa) : t + v * nf_exp(-sa);
+        float2 ov;
+        ov.x = a ? 0.f : val;
+        ov.y = a ? val : 0.f;
+        store_field_pair(A, pfield, ov);
+        lacc += double(EPI == 2 ? sa : -sa);
+      }
     }
   };
 
@@ -372,6 +418,10 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
     pout = ocol + unsigned(2 * s) * unsigned(RB);
     plane_o = lane_o;
     plane_ok = lane_ok;
+    if (EPI > 0) {
+      pfield = fcol + int64_t(2 * s) * HP;
+      pslot = col_slot;
+    }
     have_prev = true;
     // (5) the planes of the NEXT step were issued a full step ago or earlier: everything but this step's own DMAs (the
     // youngest operations: the epilogue's stores precede them) must have landed before the barrier.  A column's first step
@@ -406,6 +456,7 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
 #endif
   // ---- the last step's epilogue
   if (have_prev) epilogue((nsteps_total - 1) & 1);
+  if (EPI > 0) flush();
   wait_vm<0>();                               // no DMA may outlive the workgroup's LDS allocation
 }
 
@@ -424,6 +475,40 @@ extern "C" int nf_conv_split16_supported(const int32_t *lattice, const int32_t *
   return 1;
 }
 
+static int launch_g2(ConvArgs &A, const int32_t *lattice, int64_t B, int epi, hipStream_t stream, const char *what) {
+  A.V = 1;
+  for (int mu = 0; mu < 4; ++mu) {
+    A.L[mu] = lattice[mu]; A.k[mu] = 3;
+    A.V *= lattice[mu];
+  }
+  A.cin = 8; A.cout = 8;
+  const bool segm = lattice[3] != 32;
+  A.nitems = B * int64_t(lattice[0] / 2) * int64_t(lattice[1] / 2) * int64_t(segm ? (lattice[3] / 2 + 15) / 16 : 1);      // columns (x segments)
+  NF_REQUIRE(A.V * 32 < (int64_t(1) << 32), "%s: a sample's pair tensor must stay below 4 GiB", what);
+  NF_REQUIRE(A.nitems < (int64_t(1) << 28) - 4096, "%s: batch x columns >= 2^28, split the batch", what);
+  // one persistent workgroup per CU of an MI355X; workgroup (xcd = id & 7, j = id >> 3) takes member j of every 8th group of
+  // 32 columns (on a part with fewer CUs the surplus workgroups simply queue: there is no inter-workgroup dependency)
+  const int64_t grid = 256;
+  auto go = [&](auto kern, int lds) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      set_error("%s: cannot reserve %d B of LDS", what, lds);
+      return int(NF_ELAUNCH);
+    }
+    hipLaunchKernelGGL(kern, dim3(unsigned(grid)), dim3(512), lds, stream, A);
+    return int(NF_OK);
+  };
+  int rc;
+  if (segm) {
+    constexpr int lds = g2::Geo<true>::LDS_BYTES;
+    rc = epi == 0 ? go(&conv_g2_kernel<true, 0>, lds) : (epi == 1 ? go(&conv_g2_kernel<true, 1>, lds) : go(&conv_g2_kernel<true, 2>, lds));
+  } else {
+    constexpr int lds = g2::Geo<false>::LDS_BYTES;
+    rc = epi == 0 ? go(&conv_g2_kernel<false, 0>, lds) : (epi == 1 ? go(&conv_g2_kernel<false, 1>, lds) : go(&conv_g2_kernel<false, 2>, lds));
+  }
+  if (rc) return rc;
+  return check_launch(what);
+}
+
 extern "C" int nf_conv_fwd_split16(const void *in16, const void *wsplit, const void *bias, void *out16, int64_t B,
                                    const int32_t *lattice, int act, void *stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -435,27 +520,39 @@ extern "C" int nf_conv_fwd_split16(const void *in16, const void *wsplit, const v
   if (B == 0) return NF_OK;
   ConvArgs A{};
   A.in = in16; A.wfrag = wsplit; A.bias = bias; A.out = out16;
-  A.V = 1;
-  for (int mu = 0; mu < 4; ++mu) {
-    A.L[mu] = lattice[mu]; A.k[mu] = 3;
-    A.V *= lattice[mu];
+  A.act = act;
+  return launch_g2(A, lattice, B, 0, stream, "nf_conv_fwd_split16");
+}
+
+// Partials per sample of nf_conv_affine_split16: one per (column, segment, wave).
+static int64_t affine_split16_blocks(const int32_t *lattice) {
+  return int64_t(lattice[0] / 2) * (lattice[1] / 2) * (lattice[3] != 32 ? (lattice[3] / 2 + 15) / 16 : 1) * 8;
+}
+
+extern "C" int nf_conv_affine_split16(const void *in16, const void *wsplit, const void *bias, const void *x_active,
+                                      const void *log0, void *y, void *logj, int64_t B, const int32_t *lattice,
+                                      int active_parity, int inverse, int flags, void *workspace, size_t workspace_bytes,
+                                      void *stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  NF_REQUIRE(in16 && wsplit && x_active && y && logj && lattice, "nf_conv_affine_split16: NULL pointer");
+  const int32_t k3[4] = {3, 3, 3, 3};
+  NF_REQUIRE(nf_conv_split16_supported(lattice, k3, 8, 8, kActTanh), "nf_conv_affine_split16: lattice not supported (needs a fastest axis of 32 + 16 n sites, even other extents)");
+  NF_REQUIRE(B >= 0 && B <= 65535, "nf_conv_affine_split16: batch outside [0, 65535]");
+  if (B == 0) return NF_OK;
+  const int64_t blocks = affine_split16_blocks(lattice);
+  const size_t need = size_t(B) * size_t(blocks) * sizeof(double);
+  if (workspace == nullptr || workspace_bytes < need) {
+    set_error("nf_conv_affine_split16: workspace %zu B < %zu B needed", workspace_bytes, need);
+    return NF_EWORKSPACE;
   }
-  A.cin = 8; A.cout = 8; A.act = act;
-  const bool segm = lattice[3] != 32;
-  A.nitems = B * int64_t(lattice[0] / 2) * int64_t(lattice[1] / 2) * int64_t(segm ? (lattice[3] / 2 + 15) / 16 : 1);      // columns (x segments)
-  NF_REQUIRE(A.V * 32 < (int64_t(1) << 32), "nf_conv_fwd_split16: a sample's pair tensor must stay below 4 GiB");
-  NF_REQUIRE(A.nitems < (int64_t(1) << 31) - 4096, "nf_conv_fwd_split16: batch x columns >= 2^31, split the batch");
-  // one persistent workgroup per CU of an MI355X; workgroup (xcd = id & 7, j = id >> 3) takes member j of every 8th group of
-  // 32 columns (on a part with fewer CUs the surplus workgroups simply queue: there is no inter-workgroup dependency)
-  const int64_t grid = 256;
-  if (segm) {
-    NF_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_g2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, g2::Geo<true>::LDS_BYTES) == hipSuccess,
-               "nf_conv_fwd_split16: cannot reserve %d B of LDS", g2::Geo<true>::LDS_BYTES);
-    hipLaunchKernelGGL(conv_g2_kernel<true>, dim3(unsigned(grid)), dim3(512), g2::Geo<true>::LDS_BYTES, stream, A);
-  } else {
-    NF_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_g2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, g2::Geo<false>::LDS_BYTES) == hipSuccess,
-               "nf_conv_fwd_split16: cannot reserve %d B of LDS", g2::Geo<false>::LDS_BYTES);
-    hipLaunchKernelGGL(conv_g2_kernel<false>, dim3(unsigned(grid)), dim3(512), g2::Geo<false>::LDS_BYTES, stream, A);
-  }
-  return check_launch("conv split-fp16 hidden-layer kernel");
+  ConvArgs A{};
+  A.in = in16; A.wfrag = wsplit; A.bias = bias;
+  A.xact = static_cast<const float *>(x_active);
+  A.yout = static_cast<float *>(y);
+  A.partial = static_cast<double *>(workspace);
+  A.parity = active_parity & 1;
+  A.field16 = (flags & NF_CONV_FIELD_F16) ? 1 : 0;
+  const int rc = launch_g2(A, lattice, B, inverse ? 2 : 1, stream, "nf_conv_affine_split16");
+  if (rc) return rc;
+  return launch_finalize<float>(A.partial, blocks, log0, logj, B, stream);
 }

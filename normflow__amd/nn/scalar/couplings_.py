@@ -162,7 +162,43 @@ class ShiftCoupling_(Coupling_):
 class AffineCoupling_(Coupling_):
     """y = t + x e^{-|s|}, log|J| = -sum|s| over the active sites (couplings_.py:120-139)."""
 
+    HIDDEN_SLAB_BYTES = int(float(os.environ.get("NF_HIDDEN_SLAB_GIB", "8")) * (1 << 30))
+
+    def _fused_atom(self, inverse, x_active, x_frozen, parity, net, log0):
+        """Inference fast path on the split-fp16 chain: first layer -> pair tensor, hidden layers, and the net's last layer
+        (8 -> 2) fused with the affine map (nf_conv_affine_split16); the (t, s) tensor never reaches HBM.  None when it does
+        not apply (then: conv stack + nf_affine)."""
+        if (torch.is_grad_enabled() and (x_active.requires_grad or x_frozen.requires_grad
+                                         or any(p.requires_grad for p in net.parameters()))):
+            return None
+        if (self.propagate_density or self.channels_axis != 1 or not hasattr(net, 'hidden_and_last')
+                or not getattr(self.mask, 'pairable', False) or x_active.dtype not in (torch.float32, torch.float16)
+                or not hasattr(self.mask, 'checkerboard_parity') or x_active.dim() != 5):
+            return None
+        a = self.mask.checkerboard_parity(parity)
+        if a is None or net.conv_kwargs['out_channels'] != 2:
+            return None
+        B = x_active.shape[0]
+        v = x_active.reshape(B, -1).contiguous()
+        l0 = _hip._log0_tensor(log0, v, B)
+        hidden = max(net.conv_kwargs['hidden_sizes'] or [1])
+        val = torch.empty_like(v)
+        lj = torch.empty(B, dtype=torch.float32, device=v.device)
+        lattice = tuple(x_frozen.shape[1:])
+        for b0, b1 in self._slabs(B, hidden * v.shape[1] * 4, self.HIDDEN_SLAB_BYTES):
+            xf = x_frozen[b0:b1]
+            got = net.hidden_and_last(self.preprocess_fz(xf.float() if xf.dtype == torch.float16 else xf), last_kind='affine')
+            if got is None:
+                return None
+            h16, last, unit, split = got
+            _hip.conv_affine_split16(h16, last.weight, last.bias, v[b0:b1], None if l0 is None else l0[b0:b1], a, inverse,
+                                     lattice, out=(val[b0:b1], lj[b0:b1]))
+        return val.reshape(x_active.shape), lj
+
     def _atom(self, inverse, *, x_active, x_frozen, parity, net, log0=0):
+        fused = self._fused_atom(inverse, x_active, x_frozen, parity, net, log0)
+        if fused is not None:
+            return fused
         k = lambda v, p, l0, act, layout: _hip.AffineCouplingFn.apply(v, p, l0, act, layout, inverse)
         return self._run_atom(k, x_active, x_frozen, parity, net, log0, 2)
 

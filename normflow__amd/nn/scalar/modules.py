@@ -131,10 +131,10 @@ class ConvAct(torch.nn.Sequential):
                                 parity=compact_parity or 0)
         return x
 
-    def hidden_and_last(self, x):
-        """(hidden activations after all but the last conv, last conv module, |hidden| <= 1?) when the stack
-        maps onto the MFMA kernel and the last layer has no activation; else None.  Lets a
-        coupling fuse the last layer with its own kernel."""
+    def hidden_and_last(self, x, last_kind='rqs'):
+        """(hidden activations after all but the last conv, last conv module, |hidden| <= 1?, pair tensor?) when the stack
+        maps onto the MFMA kernel and the last layer has no activation; else None.  Lets a coupling fuse the last layer
+        with its own kernel: last_kind = 'rqs' (nf_conv_rqs) or 'affine' (nf_conv_affine_split16: only the split-fp16 chain)."""
         if self.conv_kwargs.get('pre_act') is not None or x.dim() - 2 != self.conv_kwargs['conv_dim']:
             return None
         plan = self._plan()
@@ -151,10 +151,17 @@ class ConvAct(torch.nn.Sequential):
         # split-fp16 products (nf_conv_h.hip); when it will, the last hidden layer writes its output already split
         # into fp16 (hi, lo) pairs, channel-last (one conversion per site instead of one per halo copy downstream)
         unit = len(plan) > 1 and plan[-2][1] in (_hip.ACT_CODES['tanh'], _hip.ACT_CODES['expit'])
-        split = unit and len(plan) > 2 and self._wants_split16(x, plan)
+        if last_kind == 'affine':
+            lw = plan[-1][0].weight
+            split = (unit and len(plan) > 2 and x.dtype == torch.float32 and lw.dim() == 6 and tuple(lw.shape) == (2, 8, 3, 3, 3, 3)
+                     and _hip._weights_fit_fp16(lw))
+        else:
+            split = unit and len(plan) > 2 and self._wants_split16(x, plan)
         # when every hidden layer after the first is an 8 -> 8 layer the split-fp16 two-site kernel takes, the pairs
         # are produced once by the first layer and flow through the whole stack
         chain = split and self._split16_chain(x, plan)
+        if last_kind == 'affine' and not chain:
+            return None                        # the fused affine layer exists on the pair tensor only
         lat = tuple(x.shape[2:])
         for n, (conv, act) in enumerate(plan[:-1]):
             last_hidden = n == len(plan) - 2

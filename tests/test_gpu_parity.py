@@ -1473,3 +1473,46 @@ def test_graph_replay_survives_larger_eager_calls():
         y2, l2 = net_(xs)
     y3, l3 = g(xs)
     assert torch.equal(y3, y2) and torch.equal(l3, l2) and not torch.equal(y3, y0)
+
+
+@pytest.mark.parametrize("shape,B", [((4, 2, 6, 32), 33), ((2, 2, 2, 32), 5), ((2, 4, 4, 48), 9), ((4, 4, 2, 64), 6)])
+def test_fused_affine_layer_on_the_split_chain(shape, B):
+    """nf_conv_affine_split16: the last layer (8 -> 2) of an affine coupling's net fused with the coupling, fed by the pair
+    tensor of the split-fp16 chain -- against the unfused path (fp32 conv stack + nf_affine: two roundings of the same exact
+    result) and against the fp64 oracle within north_star's 1e-5; forward, inverse (round trip through the fused kernels),
+    both parities, log0 threaded; batch-permutation invariance (the per-(column, wave) log-det partials are deterministic)."""
+    torch.manual_seed(41)
+    net = ConvAct(1, 2, 3, conv_dim=4, hidden_sizes=[8, 8], acts=['tanh', 'tanh', None]).to(DEV, torch.float32)
+    with torch.no_grad():
+        for p_ in list(net.parameters())[-2:]:
+            p_.mul_(0.3)
+    mask = EvenOddMask(shape=shape)
+    cpl = AffineCoupling_([net, net], mask=mask).to(DEV)
+    x = 1.5 * torch.randn((B,) + shape, device=DEV, dtype=torch.float32)
+    convs = [mod for mod in net if hasattr(mod, 'weight')]
+    layers = [(c.weight.detach().double().cpu(), c.bias.detach().double().cpu()) for c in convs]
+    for parity in (0, 1):
+        xa, xf = mask.purify(x, parity), mask.purify(x, 1 - parity)
+        l0 = torch.randn(B, device=DEV, dtype=torch.float32)
+        with torch.no_grad():
+            got = cpl._fused_atom(False, xa, xf, parity, net, l0)
+            assert got is not None, "the fused affine path did not apply"
+            yf, lf = got
+            with _hip.options(split16=False):
+                assert cpl._fused_atom(False, xa, xf, parity, net, l0) is None
+                yu, lu = cpl.atomic_forward(x_active=xa, x_frozen=xf, parity=parity, net=net, log0=l0)
+            assert rel(yf, yu) <= 1e-5 and rel(lf, lu) <= 1e-5, (rel(yf, yu), rel(lf, lu))
+            xb, lb = cpl._fused_atom(True, yf, xf, parity, net, lf)
+            assert rel(xb, xa) <= 2e-5 and rel(lb, l0) <= 1e-5 * max(1.0, float(lf.abs().max())), (rel(xb, xa), rel(lb, l0))
+            perm = torch.randperm(B, device=DEV)
+            yp, lp = cpl._fused_atom(False, xa[perm], xf[perm], parity, net, l0[perm])
+            assert torch.equal(yp, yf[perm]) and torch.equal(lp, lf[perm])
+        nb = min(B, 4)
+        out = O.conv_act(xf[:nb].double().cpu().unsqueeze(1), layers, ['tanh', 'tanh', None])
+        yo, lo = O.affine_coupling_atom(xa[:nb].double().cpu(), out, O.channel_mask(shape, parity), log0=l0[:nb].double().cpu())
+        assert rel(yf[:nb], yo) <= 1e-5 and rel(lf[:nb], lo) <= 1e-5, (rel(yf[:nb], yo), rel(lf[:nb], lo))
+    # the block-level API takes the fused path under no_grad and the differentiable path otherwise
+    with torch.no_grad():
+        y1, l1 = cpl(x)
+    y2, l2 = cpl(x.clone().requires_grad_(True))
+    assert rel(y1, y2) <= 1e-5 and rel(l1, l2) <= 1e-5

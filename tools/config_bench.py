@@ -49,3 +49,6 @@ if __name__ == "__main__":
     run("c4 32^4, 8 rqs (per-GPU share)", (32,) * 4, ['rqs'] * 8, 128)
     run("c5 48^4, 8 affine + 8 rqs", (48,) * 4, ['affine', 'rqs'] * 8, 8)
     run("   32^4, 8 affine + 8 rqs", (32,) * 4, ['affine', 'rqs'] * 8, 40)
+    run("   48^4, 8 rqs", (48,) * 4, ['rqs'] * 8, 16)
+    run("   32^4, 8 rqs (same sites: B=81)", (32,) * 4, ['rqs'] * 8, 81)
+    run("   64^4, 8 rqs", (64,) * 4, ['rqs'] * 8, 8)
