@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NF_VERSION 200 /* 0.2.0 */
+#define NF_VERSION 201 /* 0.2.0 */
 
 /* NF_F16 (nf_rqs_fwd / nf_rqs_inv with knots_len 4/8/16, nf_affine_fwd / nf_affine_inv): x, params and y are IEEE half, the arithmetic is fp32 and
  * log0 / logj are fp32 ("fp16 params / fp32 log-det accumulate", BASELINE config 5). */
@@ -138,6 +138,33 @@ int nf_rqs_inv_vjp(const void *x, const void *params, const uint8_t *mask,
                    const void *grad_out, const void *grad_logj, void *grad_in,
                    void *grad_params, int64_t B, int64_t V, const nf_rqs_opts *opts,
                    const nf_strides *strides, int dtype, void *stream);
+
+/* ---- K2s: the spline object of a coupling layer -------------------------------
+ * What a user of the reference reaches through RQSplineCoupling_.make_spline / _hack
+ * (src/nn/scalar/couplings_.py:202-262) and through propagate_density
+ * (src/nn/_core.py:19,38-42): the derivative of every site instead of only its summed log.
+ *
+ * nf_rqs_fwd_sites / nf_rqs_inv_sites are nf_rqs_fwd / nf_rqs_inv (same arguments, same y and
+ * logj) and additionally write site_out (B,V) of dtype: with NF_SITES_LOG the log-derivative
+ * log|dy/dx| (fwd) or log|dx/dy| (inv) of every active site, with NF_SITES_DERIVATIVE the
+ * derivative itself (`g` of spline.py:87-123 with grad=True; the inverse returns 1/g as the
+ * reference's spline.backward does, spline.py:222-287); 0 at frozen sites.  NF_F32 / NF_F64.
+ *
+ * nf_rqs_knots writes the knot tensors make_spline builds from the logits, before the boundary
+ * augmentation of spline.py:458-532: knots (B, 3m, V) of dtype = knots_x (m planes), knots_y (m),
+ * knots_d (m); fixed knots_x / knots_y are copied through.  params in the full layout (B, C, V).
+ * The arithmetic is the coupling kernels' own: these are the knots they evaluate. */
+enum nf_sites_mode { NF_SITES_LOG = 1, NF_SITES_DERIVATIVE = 2 };
+int nf_rqs_fwd_sites(const void *x, const void *params, const uint8_t *mask, const void *log0,
+                     void *y, void *logj, void *site_out, int site_mode, int64_t B, int64_t V,
+                     const nf_rqs_opts *opts, const nf_strides *strides, void *workspace,
+                     size_t workspace_bytes, int dtype, void *stream);
+int nf_rqs_inv_sites(const void *y, const void *params, const uint8_t *mask, const void *log0,
+                     void *x, void *logj, void *site_out, int site_mode, int64_t B, int64_t V,
+                     const nf_rqs_opts *opts, const nf_strides *strides, void *workspace,
+                     size_t workspace_bytes, int dtype, void *stream);
+int nf_rqs_knots(const void *params, void *knots, int64_t B, int64_t V, const nf_rqs_opts *opts,
+                 int dtype, void *stream);
 
 /* ---- K1: affine / shift coupling --------------------------------------------
  * Replaces couplings_.py:123-139 (affine: chunk, 2 purify, abs, exp, fma, sum)

@@ -40,6 +40,7 @@ class Strides(C.Structure):
 _P, _I64, _I, _SZ, _D = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_double
 _MAP_ARGS = [_P, _P, _P, _P, _P, _P, _I64, _I64, C.POINTER(RqsOpts), C.POINTER(Strides), _P, _SZ, _I, _P]
 _VJP_ARGS = [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, C.POINTER(RqsOpts), C.POINTER(Strides), _I, _P]
+_SITES_ARGS = [_P, _P, _P, _P, _P, _P, _P, _I, _I64, _I64, C.POINTER(RqsOpts), C.POINTER(Strides), _P, _SZ, _I, _P]
 PROTOTYPES = {
     "nf_version": (C.c_int, []),
     "nf_last_error_string": (C.c_char_p, []),
@@ -48,6 +49,9 @@ PROTOTYPES = {
     "nf_workspace_bytes": (_SZ, [_I64, _I64]),
     "nf_rqs_fwd": (_I, _MAP_ARGS),
     "nf_rqs_inv": (_I, _MAP_ARGS),
+    "nf_rqs_fwd_sites": (_I, _SITES_ARGS),
+    "nf_rqs_inv_sites": (_I, _SITES_ARGS),
+    "nf_rqs_knots": (_I, [_P, _P, _I64, _I64, C.POINTER(RqsOpts), _I, _P]),
     "nf_rqs_fwd_vjp": (_I, _VJP_ARGS),
     "nf_rqs_inv_vjp": (_I, _VJP_ARGS),
     "nf_affine_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _P, _SZ, _I, _P]),
@@ -218,6 +222,46 @@ def _rqs_call(fn_name, v, params, mask, log0, opts, strides, B, V):
                                       C.byref(strides) if strides is not None else None, _ptr(ws),
                                       ws.numel(), _dtype_code(v), _stream()), fn_name)
     return out, logj
+
+
+SITES_LOG, SITES_DERIVATIVE = 1, 2       # nf_sites_mode
+
+
+def rqs_sites(v, params, mask, log0, opts, inverse, mode=SITES_LOG):
+    """nf_rqs_fwd_sites / nf_rqs_inv_sites: (value, logJ, per-site log-derivative or derivative).  Inference only
+    (no autograd): the spline-object / propagate_density path of the reference (couplings_.py:202-209, _core.py:38-42)."""
+    _require_device(v, params, mask, log0)
+    if v.dtype not in (torch.float32, torch.float64) or params.dtype != v.dtype:
+        raise TypeError(f"per-site derivatives are built for float32 / float64 fields; got {v.dtype} / {params.dtype}")
+    lib = load()
+    B, V = v.shape
+    v, params = v.detach().contiguous(), params.detach().contiguous()
+    out, sites = torch.empty_like(v), torch.empty_like(v)
+    logj = torch.empty(B, dtype=v.dtype, device=v.device)
+    ws = _workspace(min(B, MAX_B), V, v.device)
+    fn = lib.nf_rqs_inv_sites if inverse else lib.nf_rqs_fwd_sites
+    for b0 in range(0, B, MAX_B):
+        b1 = min(B, b0 + MAX_B)
+        l0 = log0[b0:b1] if log0 is not None else None
+        _check(fn(_ptr(v[b0:b1]), _ptr(params[b0:b1]), _ptr(mask), _ptr(l0), _ptr(out[b0:b1]), _ptr(logj[b0:b1]),
+                  _ptr(sites[b0:b1]), int(mode), b1 - b0, V, C.byref(opts), None, _ptr(ws), ws.numel(),
+                  _dtype_code(v), _stream()), "nf_rqs_sites")
+    return out, logj, sites
+
+
+def rqs_knots(params, opts):
+    """nf_rqs_knots: (B, C, V) logits -> (B, 3m, V) = knots_x | knots_y | knots_d, before boundary augmentation."""
+    _require_device(params)
+    if params.dtype not in (torch.float32, torch.float64):
+        raise TypeError(f"knots are built for float32 / float64 logits; got {params.dtype}")
+    params = params.detach().contiguous()
+    B, _, V = params.shape
+    knots = torch.empty(B, 3 * opts.m, V, dtype=params.dtype, device=params.device)
+    for b0 in range(0, B, 65535):
+        b1 = min(B, b0 + 65535)
+        _check(load().nf_rqs_knots(_ptr(params[b0:b1]), _ptr(knots[b0:b1]), b1 - b0, V, C.byref(opts),
+                                   _dtype_code(params), _stream()), "nf_rqs_knots")
+    return knots
 
 
 def _rqs_vjp_call(fn_name, x, params, mask, gout, glogj, opts, strides, B, V):

@@ -34,6 +34,8 @@ struct RqsArgs {
   const void *grad_logj;    // VJP only
   void *grad_in;            // VJP only
   void *grad_params;        // VJP only
+  void *site_out;           // optional (B,V): the derivative (site_mode 2) or its log (1) of every site, 0 at frozen sites
+  int site_mode;
   int64_t V;                // sites per sample
   int64_t Vp;               // site extent of params: V (full) or V/2 (pair)
   int64_t units;            // work units per sample: V (full) or V/2 (pair)
@@ -100,6 +102,18 @@ __global__ __launch_bounds__(kBlock) void rqs_kernel(RqsArgs A) {
       reinterpret_cast<typename Pair2<S>::type *>(yout)[u] = o;
     } else {
       yout[u] = S(val);
+    }
+    if (A.site_out) {         // what the reference's spline object returns with grad=True (spline.py:87-123), per site
+      const T sv = active ? (A.site_mode == 2 ? nf_exp(logd) : logd) : T(0);
+      S *so = static_cast<S *>(A.site_out) + int64_t(b) * A.V;
+      if (PAIR) {
+        typename Pair2<S>::type o;
+        o.x = S(off ? T(0) : sv);
+        o.y = S(off ? sv : T(0));
+        reinterpret_cast<typename Pair2<S>::type *>(so)[u] = o;
+      } else {
+        so[u] = S(sv);
+      }
     }
     acc += double(logd);
   }
@@ -170,6 +184,44 @@ __global__ __launch_bounds__(kBlock) void rqs_vjp_kernel(RqsArgs A) {
       gin[u] = gi;
     }
   }
+}
+
+// The knots a site's logits stand for -- the tensors `RQSplineCoupling_.make_spline` hands to `RQSpline`
+// (couplings_.py:211-262), before the boundary augmentation: out[b][0..m) = knots_x, [m..2m) = knots_y, [2m..3m) = knots_d,
+// each a plane of V sites.  Same arithmetic, in the same order, as scan_bins above: these ARE the knots the coupling
+// kernels evaluate.  An inspection path (three passes over the logits, no registers arrays): not tuned.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void rqs_knots_kernel(RqsArgs A) {
+  const int b = blockIdx.y;
+  const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (u >= A.V) return;
+  const int m = A.P.m, nb = m - 1;
+  const T *fx = static_cast<const T *>(A.P.fx), *fy = static_cast<const T *>(A.P.fy);
+  const ChanMap cm = chan_map(m, fx != nullptr, fy != nullptr);
+  const T *__restrict__ par = static_cast<const T *>(A.params) + int64_t(b) * A.p_bs + u;
+  T *__restrict__ out = static_cast<T *>(A.y) + int64_t(b) * 3 * m * A.V + u;
+  for (int blk = 0; blk < 2; ++blk) {
+    const T *fixed = blk ? fy : fx;
+    const T lo = T(blk ? A.P.ylo : A.P.xlo), width = T(blk ? A.P.yhi : A.P.xhi) - lo;
+    T *o = out + int64_t(blk) * m * A.V;
+    if (fixed) {
+      for (int k = 0; k < m; ++k) o[int64_t(k) * A.V] = fixed[k];
+      continue;
+    }
+    const T *a = par + int64_t(blk ? cm.oy : cm.ox) * A.V;
+    T amax = a[0];
+    for (int k = 1; k < nb; ++k) amax = Num<T>::max(amax, a[int64_t(k) * A.V]);
+    T sum = T(0);
+    for (int k = 0; k < nb; ++k) sum += Num<T>::exp2((a[int64_t(k) * A.V] - amax) * Num<T>::kLog2e);
+    const T w = width / sum;
+    T c = lo;
+    o[0] = c;
+    for (int k = 0; k < nb; ++k) {
+      c += Num<T>::exp2((a[int64_t(k) * A.V] - amax) * Num<T>::kLog2e) * w;
+      o[int64_t(k + 1) * A.V] = c;
+    }
+  }
+  for (int k = 0; k < m; ++k) out[int64_t(2 * m + k) * A.V] = softplus2(par[int64_t(cm.od + k) * A.V]);
 }
 
 // ------------------------------------------------------------------ launchers
@@ -268,10 +320,12 @@ static int dispatch(const RqsArgs &A, dim3 grid, int block, hipStream_t stream) 
 template <typename T, typename S, int MODE>
 static int run_map(const void *in, const void *params, const uint8_t *mask, const void *log0, void *out,
                    void *logj, int64_t B, int64_t V, const nf_rqs_opts *o, const nf_strides *st,
-                   void *ws, size_t ws_bytes, hipStream_t stream) {
+                   void *ws, size_t ws_bytes, hipStream_t stream, void *site_out = nullptr, int site_mode = 0) {
   RqsArgs A{};
   int rc = fill_args(A, B, V, o, st, mask);
   if (rc) return rc;
+  A.site_out = site_out;
+  A.site_mode = site_mode;
   NF_REQUIRE(in && params && out && logj, "nf_rqs: NULL tensor pointer");
   if (B == 0) return NF_OK;
   const int block = pick_block<T>(A);
@@ -357,4 +411,56 @@ extern "C" int nf_rqs_inv_vjp(const void *x, const void *params, const uint8_t *
   if (dtype == NF_F64) return run_vjp<double, kInv>(x, params, mask, grad_out, grad_logj, grad_in, grad_params, B, V, opts, strides, s);
   set_error("nf_rqs_inv_vjp: unsupported dtype %d", dtype);
   return NF_EINVAL;
+}
+
+// Per-site derivatives beside the summed log-det: what the reference's spline object returns with grad=True
+// (src/lib/spline/spline.py:87-123) and what Module_.sum_density passes through when propagate_density is set
+// (src/nn/_core.py:38-42).
+static int rqs_sites(int inverse, const void *in, const void *params, const uint8_t *mask, const void *log0, void *out,
+                     void *logj, void *site_out, int site_mode, int64_t B, int64_t V, const nf_rqs_opts *opts,
+                     const nf_strides *strides, void *workspace, size_t workspace_bytes, int dtype, void *stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  NF_REQUIRE(site_out != nullptr, "nf_rqs_sites: site_out is NULL");
+  NF_REQUIRE(site_mode == NF_SITES_LOG || site_mode == NF_SITES_DERIVATIVE, "nf_rqs_sites: site_mode %d", site_mode);
+  if (dtype == NF_F32)
+    return inverse ? run_map<float, float, kInv>(in, params, mask, log0, out, logj, B, V, opts, strides, workspace, workspace_bytes, s, site_out, site_mode)
+                   : run_map<float, float, kFwd>(in, params, mask, log0, out, logj, B, V, opts, strides, workspace, workspace_bytes, s, site_out, site_mode);
+  if (dtype == NF_F64)
+    return inverse ? run_map<double, double, kInv>(in, params, mask, log0, out, logj, B, V, opts, strides, workspace, workspace_bytes, s, site_out, site_mode)
+                   : run_map<double, double, kFwd>(in, params, mask, log0, out, logj, B, V, opts, strides, workspace, workspace_bytes, s, site_out, site_mode);
+  set_error("nf_rqs_sites: unsupported dtype %d", dtype);
+  return NF_EINVAL;
+}
+
+extern "C" int nf_rqs_fwd_sites(const void *x, const void *params, const uint8_t *mask, const void *log0, void *y,
+                                void *logj, void *site_out, int site_mode, int64_t B, int64_t V,
+                                const nf_rqs_opts *opts, const nf_strides *strides, void *workspace,
+                                size_t workspace_bytes, int dtype, void *stream) {
+  return rqs_sites(0, x, params, mask, log0, y, logj, site_out, site_mode, B, V, opts, strides, workspace, workspace_bytes, dtype, stream);
+}
+
+extern "C" int nf_rqs_inv_sites(const void *y, const void *params, const uint8_t *mask, const void *log0, void *x,
+                                void *logj, void *site_out, int site_mode, int64_t B, int64_t V,
+                                const nf_rqs_opts *opts, const nf_strides *strides, void *workspace,
+                                size_t workspace_bytes, int dtype, void *stream) {
+  return rqs_sites(1, y, params, mask, log0, x, logj, site_out, site_mode, B, V, opts, strides, workspace, workspace_bytes, dtype, stream);
+}
+
+extern "C" int nf_rqs_knots(const void *params, void *knots, int64_t B, int64_t V, const nf_rqs_opts *opts, int dtype,
+                            void *stream) {
+  NF_REQUIRE(opts != nullptr, "nf_rqs_knots: opts is NULL");
+  NF_REQUIRE(params && knots, "nf_rqs_knots: NULL tensor pointer");
+  NF_REQUIRE(opts->layout == NF_LAYOUT_FULL, "nf_rqs_knots: params must be in the full layout (B, C, V)");
+  NF_REQUIRE(dtype == NF_F32 || dtype == NF_F64, "nf_rqs_knots: unsupported dtype %d", dtype);
+  static const uint8_t unused_mask = 1;
+  RqsArgs A{};
+  int rc = fill_args(A, B, V, opts, nullptr, &unused_mask);
+  if (rc) return rc;
+  if (B == 0 || V == 0) return NF_OK;
+  A.params = params;
+  A.y = knots;
+  const dim3 grid(unsigned((V + kBlock - 1) / kBlock), unsigned(B));
+  if (dtype == NF_F32) hipLaunchKernelGGL(rqs_knots_kernel<float>, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), A);
+  else hipLaunchKernelGGL(rqs_knots_kernel<double>, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), A);
+  return check_launch("rqs knots kernel");
 }

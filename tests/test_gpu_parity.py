@@ -1516,3 +1516,119 @@ def test_fused_affine_layer_on_the_split_chain(shape, B):
         y1, l1 = cpl(x)
     y2, l2 = cpl(x.clone().requires_grad_(True))
     assert rel(y1, y2) <= 1e-5 and rel(l1, l2) <= 1e-5
+
+
+# ----------------------------------------------------------------------------- the spline object of a coupling layer
+SPLINE_EXTRAPS = [{}, {'left': 'linear', 'right': 'linear'}, {'left': 'anti'}, {'left': 'anti', 'right': 'linear'},
+                  {'right': 'anti'}]
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("m", [2, 5, 16])
+def test_make_spline_knots_and_values_vs_oracle(m, dtype):
+    """`RQSplineCoupling_.make_spline(out)` (couplings_.py:211-262): the knot tensors the object shows (nf_rqs_knots + the
+    boundary augmentation of spline.py:458-532) and spline(x, grad=True) / spline.backward(y, grad=True) at EVERY site
+    (nf_rqs_fwd_sites / nf_rqs_inv_sites) against the oracle's knots_from_logits / augment_knots / rqs_evaluate /
+    rqs_invert.  fp64 1e-9; fp32 1e-5 on knots and values, derivative 1e-4 (it is exp of a log the kernel holds to 1e-5)."""
+    shape, B = (4, 6, 5), 3
+    x, out = _rand_case(shape, B, m, 400 + m, dtype, x_std=1.5)
+    lim = dict(xlim=(-2.0, 2.0), ylim=(-1.5, 2.5))
+    tol = 1e-9 if dtype == torch.float64 else 1e-5
+    mask = EvenOddMask(shape=shape)
+    for extrap in SPLINE_EXTRAPS:
+        cpl = RQSplineCoupling_([torch.nn.Identity()], mask=mask, extrap=extrap, **lim)
+        sp = cpl.make_spline(out.to(DEV, dtype))
+        kx, ky, kd = O.knots_from_logits(out, **lim)
+        kx, ky, kd = O.augment_knots(kx, ky, kd, axis=1, **extrap)
+        assert sp.knots_len == kx.shape[1] and tuple(sp.knots_shape) == tuple(kx.shape)
+        assert rel(sp.knots_x, kx) <= tol and rel(sp.knots_y, ky) <= tol and rel(sp.knots_d, kd) <= tol
+        # inside the knot range, and for the extrapolating variants also beyond it
+        v = (2.0 * x).unsqueeze(1)
+        v = v.clamp(min=-1e9 if extrap.get('left') else -1.99, max=1e9 if extrap.get('right') else 1.99)
+        if 'anti' in extrap.values() and len(extrap) == 1:      # the mirror image must stay inside the side with no rule
+            v = v.clamp(-5.9, 5.9)
+        fo, go = O.rqs_evaluate(kx, ky, kd, v, axis=1)
+        f, g = sp(v.to(DEV, dtype), grad=True)
+        assert f.shape == v.shape and g.shape == v.shape
+        assert rel(f, fo) <= tol and rel(g, go) <= 10 * tol
+        assert rel(sp(v.squeeze(1).to(DEV, dtype), squeezed=True), fo.squeeze(1)) <= tol
+        w = fo.clamp(min=-1e9 if extrap.get('left') else -1.49, max=1e9 if extrap.get('right') else 2.49)
+        bo, hgo = O.rqs_invert(kx, ky, kd, w, axis=1)
+        bk, hg = sp.backward(w.to(DEV, dtype), grad=True)
+        assert rel(bk, bo) <= 50 * tol and rel(hg, hgo) <= 50 * tol
+
+
+def test_make_spline_fixed_knots_and_channels_axis():
+    """Fixed 1-D knots_x / knots_y are copied through to every site; a channels axis other than 1 is honoured."""
+    shape, B, m = (6, 4), 2, 5
+    kxf = torch.tensor([-2.0, -0.7, 0.1, 0.9, 2.0], dtype=torch.float64, device='cpu')
+    torch.manual_seed(11)
+    out = 0.5 * torch.randn((B, 2 * m - 1) + shape, dtype=torch.float64, device='cpu')
+    x = torch.randn((B, 1) + shape, dtype=torch.float64, device='cpu').clamp(-1.9, 1.9)
+    mask = EvenOddMask(shape=shape)
+    cpl = RQSplineCoupling_([torch.nn.Identity()], mask=mask, xlim=(-2.0, 2.0), ylim=(-2.0, 2.0), knots_x=kxf)
+    sp = cpl.make_spline(out.to(DEV))
+    kx, ky, kd = O.knots_from_logits(out, (-2.0, 2.0), (-2.0, 2.0), knots_x=kxf)
+    assert rel(sp.knots_x, O._bcast_like(kx, out).expand_as(ky)) == 0.0
+    assert rel(sp.knots_y, ky) <= 1e-12 and rel(sp.knots_d, kd) <= 1e-12
+    fo, go = O.rqs_evaluate(O._bcast_like(kx, out).expand_as(ky), ky, kd, x, axis=1)
+    f, g = sp(x.to(DEV), grad=True)
+    assert rel(f, fo) <= 1e-10 and rel(g, go) <= 1e-9
+    # channels last
+    cpl2 = RQSplineCoupling_([torch.nn.Identity()], mask=mask, xlim=(-2.0, 2.0), ylim=(-2.0, 2.0), knots_x=kxf,
+                             channels_axis=-1)
+    sp2 = cpl2.make_spline(out.movedim(1, -1).contiguous().to(DEV))
+    assert tuple(sp2.knots_y.shape) == (B,) + shape + (m,)
+    assert rel(sp2.knots_y.movedim(-1, 1), ky) <= 1e-12
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_hack_and_propagate_density(dtype):
+    """`_hack` (couplings_.py:202-209) and propagate_density (nn/_core.py:19,38-42): per-site log-derivatives, zero off the
+    active sublattice, against the oracle's per-site log g; their sum over the sites is the layer's log|J| (same kernel
+    arithmetic, summed in the other order: 1e-12 / 1e-6 relative)."""
+    torch.manual_seed(5)
+    shape, B, m = (4, 6, 8), 3, 8
+    net = ConvAct(1, 3 * m - 2, 3, conv_dim=3, hidden_sizes=[4], acts=['tanh', None]).to(DEV, dtype)
+    mask = EvenOddMask(shape=shape)
+    opts = dict(xlim=(-3.0, 3.0), ylim=(-3.0, 3.0), extrap={'left': 'linear', 'right': 'linear'})
+    cpl = RQSplineCoupling_([net, net], mask=mask, **opts).to(DEV)
+    x = 1.5 * torch.randn((B,) + shape, device=DEV, dtype=dtype)
+    convs = [mod for mod in net if hasattr(mod, 'weight')]
+    layers = [(c.weight.double().cpu(), c.bias.double().cpu()) for c in convs]
+    tol = 1e-9 if dtype == torch.float64 else 1e-5
+    for parity in (0, 1):
+        am = O.channel_mask(shape, parity)
+        xa, xf = x * am.to(DEV, dtype), x * (1 - am).to(DEV, dtype)
+        spline, fx, logg = cpl._hack(x_active=xa, x_frozen=xf, parity=parity, net=net)
+        out = O.conv_act(xf.double().cpu().unsqueeze(1), layers, ['tanh', None])
+        kx, ky, kd = O.knots_from_logits(out, opts['xlim'], opts['ylim'])
+        kx, ky, kd = O.augment_knots(kx, ky, kd, axis=1, **opts['extrap'])
+        fo, go = O.rqs_evaluate(kx, ky, kd, xa.double().cpu().unsqueeze(1), axis=1)
+        assert rel(fx, fo.squeeze(1) * am) <= tol
+        assert rel(logg, torch.log(go.squeeze(1)) * am) <= tol
+        assert float(logg[:, am == 0].abs().max()) == 0.0 and float(fx[:, am == 0].abs().max()) == 0.0
+        assert rel(spline.knots_d, kd) <= tol
+        with torch.no_grad():
+            y, lj = cpl.atomic_forward(x_active=xa, x_frozen=xf, parity=parity, net=net, log0=0)
+        assert rel(fx, y) <= (1e-12 if dtype == torch.float64 else 1e-6)
+        assert rel(logg.reshape(B, -1).double().sum(1), lj) <= (1e-12 if dtype == torch.float64 else 2e-6)
+    # propagate_density: whole block, forward and inverse, log0 a per-site tensor
+    with torch.no_grad():
+        y_ref, lj_ref = cpl(x)
+        cpl.propagate_density = True
+        try:
+            y, dens = cpl(x)
+            assert dens.shape == x.shape
+            assert torch.equal(y, y_ref)
+            assert rel(dens.reshape(B, -1).double().sum(1), lj_ref) <= (1e-12 if dtype == torch.float64 else 2e-6)
+            xb, back = cpl.backward(y, dens)
+            assert rel(xb, x) <= 100 * tol and float(back.abs().max()) <= 100 * tol
+        finally:
+            cpl.propagate_density = False
+    with pytest.raises(NotImplementedError):
+        cpl.propagate_density = True
+        try:
+            cpl(x.clone().requires_grad_(True))
+        finally:
+            cpl.propagate_density = False
