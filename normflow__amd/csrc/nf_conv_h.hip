@@ -64,6 +64,12 @@ static_assert(lds_bytes<true>() <= 160 * 1024, "two item images and the logit sc
 
 }  // namespace h
 
+#ifndef NF_H_DMA_EARLY
+#define NF_H_DMA_EARLY NROW
+#endif
+#ifndef NF_H_EPI
+#define NF_H_EPI 1          // 1: the mover's spline pass with the bin fetched by index (rqs_site_pt), 0: the generic rqs_site
+#endif
 #if !defined(NF_DIAG) || !defined(NF_H_ABL)
 #undef NF_H_ABL
 #define NF_H_ABL 0      // timing ablations of the compute waves (diagnostic builds only, make DIAG=1 with -DNF_H_ABL=..): 1 no fragment reads, 2 no reduction
@@ -77,6 +83,102 @@ __device__ __forceinline__ void static_for(F &&f) {
     f(std::integral_constant<int, LO>{});
     static_for<LO + 1, HI>(f);
   }
+}
+
+// The mover's spline pass: rqs_site (nf_rqs_core.h) for m = 16 free knots with the logits of the site in an LDS column
+// (`col[c * PTS]`, c = 0..45), restated so that the bin is FOUND by the scan and FETCHED by its index: the scan carries the
+// two running knots and a counter (2 FMA-able adds, 1 compare, 2 selects, 1 add per knot) instead of selecting seven values
+// per knot, and the bin's width / height numerators and the two derivative logits are read back from the column at
+// [j] -- 34 LDS reads and ~300 vector instructions per site where the generic form takes 46 and ~450.  Same operations
+// in the same order wherever a value is formed (running sums, widths as numerator x scale); two roundings differ from the
+// generic form: the softmax argument is one FMA, and quotients sharing a divisor share its reciprocal (both ~1e-7
+// relative; the parity tests hold the fused layer to the unfused one and to the oracle at the same bounds as before).
+// The mover's two passes per item are what it has to hide in an MFMA phase.
+template <bool INV>
+__device__ __forceinline__ void rqs_site_pt(const lds_f *col, const RqsParams &A, float v, float &val, float &logd) {
+  using namespace h;
+  constexpr int NB = M - 1, OX = 0, OY = NB, OD = 2 * NB;
+  const float xlo = float(A.xlo), W = float(A.xhi) - float(A.xlo), ylo = float(A.ylo), H = float(A.yhi) - float(A.ylo);
+  const float in_lo = INV ? ylo : xlo, in_hi = INV ? ylo + H : xlo + W;
+  const float out_lo = INV ? xlo : ylo, out_hi = INV ? xlo + W : ylo + H;
+  const bool refl_l = (A.el == NF_EXTRAP_ANTI) && (v < in_lo);
+  const bool refl_r = (A.er == NF_EXTRAP_ANTI) && (v > in_hi);
+  v = refl_l ? 2.f * in_lo - v : (refl_r ? 2.f * in_hi - v : v);
+  float a[2 * NB];
+#pragma unroll
+  for (int c = 0; c < 2 * NB; ++c) a[c] = col[c * PTS];
+  float amax = a[OX], bmax = a[OY];
+#pragma unroll
+  for (int k = 1; k < NB; ++k) {
+    amax = Num<float>::max(amax, a[OX + k]);
+    bmax = Num<float>::max(bmax, a[OY + k]);
+  }
+  // exp(a - max) as exp2(a log2e - max log2e): one FMA per logit (the generic form subtracts, then scales)
+  const float am2 = -amax * Num<float>::kLog2e, bm2 = -bmax * Num<float>::kLog2e;
+  float sa = 0.f, sb = 0.f;
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    a[OX + k] = Num<float>::exp2(__builtin_fmaf(a[OX + k], Num<float>::kLog2e, am2));
+    sa += a[OX + k];
+  }
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    a[OY + k] = Num<float>::exp2(__builtin_fmaf(a[OY + k], Num<float>::kLog2e, bm2));
+    sb += a[OY + k];
+  }
+  const float wx = W / sa, wy = H / sb;
+  // running knots; knot k (k = 1..NB-1) strictly below the value moves the bin up
+  float cx = xlo + a[OX] * wx, cy = ylo + a[OY] * wy;
+  float x0 = xlo, y0 = ylo;
+  int j = 0;
+#pragma unroll
+  for (int k = 1; k < NB; ++k) {
+    const bool sel = (INV ? cy : cx) < v;
+    x0 = sel ? cx : x0;
+    y0 = sel ? cy : y0;
+    j += sel ? 1 : 0;
+    cx = cx + a[OX + k] * wx;
+    cy = cy + a[OY + k] * wy;
+  }
+  const float xe = cx, ye = cy;      // last knot as accumulated (the reference's cumsum end)
+  const lds_f *cj = col + j * PTS;
+  const float bw = Num<float>::exp2(__builtin_fmaf(cj[OX * PTS], Num<float>::kLog2e, am2)) * wx;
+  const float bh = Num<float>::exp2(__builtin_fmaf(cj[OY * PTS], Num<float>::kLog2e, bm2)) * wy;
+  const float c0 = cj[OD * PTS], c1 = cj[(OD + 1) * PTS];
+  const bool tail_l = (A.el == NF_EXTRAP_LINEAR) && !(in_lo < v);
+  const bool tail_r = (A.er == NF_EXTRAP_LINEAR) && ((INV ? ye : xe) < v);
+  const float d0 = softplus2(c0), d1 = softplus2(c1);
+  const float ibw = 1.f / bw;         // one correctly rounded reciprocal for the slope and for theta, one for the two
+  const float sl = bh * ibw;          // quotients by den (the generic form divides four times: ~10 instructions each)
+  const float curv = d0 + d1 - 2.f * sl;
+  float th, g;
+  if (!INV) {
+    th = (v - x0) * ibw;
+    const float t1 = th * (1.f - th);
+    const float den = sl + curv * t1, iden = 1.f / den;
+    val = y0 + bh * (sl * th * th + d0 * t1) * iden;
+    const float P = d1 * th * th + 2.f * sl * t1 + d0 * (1.f - th) * (1.f - th);
+    g = sl * sl * P * (iden * iden);
+    val = tail_l ? ylo + d0 * (v - xlo) : (tail_r ? ye + d1 * (v - xe) : val);
+    g = tail_l ? d0 : (tail_r ? d1 : g);
+    logd = nf_log(g);
+  } else {
+    const float eta = (v - y0) / bh;
+    const float a2 = -curv * eta + d0 - sl;
+    const float bb = a2 + sl;
+    const float a0 = sl * eta;
+    const float disc = Num<float>::sqrt(Num<float>::max(bb * bb - 4.f * a0 * a2, 0.f));
+    th = (bb >= 0.f) ? 2.f * a0 / (bb + disc) : (bb - disc) / (2.f * a2);
+    const float t1 = th * (1.f - th);
+    const float den = sl + curv * t1;
+    const float P = d1 * th * th + 2.f * sl * t1 + d0 * (1.f - th) * (1.f - th);
+    g = sl * sl * P / (den * den);
+    val = x0 + bw * th;
+    val = tail_l ? xlo + (v - ylo) / d0 : (tail_r ? xe + (v - ye) / d1 : val);
+    g = tail_l ? d0 : (tail_r ? d1 : g);
+    logd = -nf_log(g);
+  }
+  val = refl_l ? 2.f * out_lo - val : (refl_r ? 2.f * out_hi - val : val);
 }
 
 template <int FUSE, bool SEGM>
@@ -405,11 +507,15 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       bool pok;
       const int64_t pair = pair_of(b, o, pass, pok);
       const float2 xv = xpre[pass];
+      float val, logd;
+#if NF_H_EPI
+      rqs_site_pt<FUSE == 2>(ptl + u, A.P, offp ? xv.y : xv.x, val, logd);
+#else
       RegCol<float, C> a;
 #pragma unroll
       for (int c = 0; c < C; ++c) a[c] = ptl[c * PTS + u];
-      float val, logd;
       rqs_site<float, M, FUSE == 2>(a, A.P, offp ? xv.y : xv.x, val, logd);
+#endif
       float2 ov;
       ov.x = offp ? 0.f : val;
       ov.y = offp ? val : 0.f;
@@ -431,12 +537,15 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   // 16-byte LDS stores per item used to take ~13 % of the kernel from the compute waves' fragment reads.
   const unsigned lds0m = unsigned(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char *)smem_h));
   const unsigned lane16 = unsigned(lane * 16);
-  int dma_off = 0;                              // lane l: site offset of halo row l of the item being brought in
-  const unsigned char *dma_src = nullptr;
-  unsigned lane_d = lane16, lane_d2 = 0;         // per-lane source offsets inside a row of the pair tensor (per item when SEGM)
+  // Source of halo row (z0, z1, z2): sample base + 32 (x0 L1 L2 L3 + x1 L2 L3 + x2 L3) bytes -- separable, so an item costs
+  // 16 scalar bases (z0, z1) and 4 per-lane offsets (z2, with the lane's place in the row folded in) and a row costs
+  // nothing but its LDS address and the instruction (4 scalar instructions where a row offset read out of a lane and a
+  // 64-bit address built per row were 8).
+  const unsigned char *dma_ab[H0 * H1];          // uniform
+  unsigned dma_v[H2], dma_v2[H2];               // per lane: main piece / (SEGM) the 17th slots, lanes 0..3
   auto dma_open = [&](int b, const int (&o)[4]) {
-    dma_off = row_offsets(o);
-    dma_src = static_cast<const unsigned char *>(A.in) + int64_t(b) * A.V * 32;
+    const unsigned char *base = static_cast<const unsigned char *>(A.in) + int64_t(b) * A.V * 32;
+    unsigned lane_d = lane16, lane_d2 = 0;       // per-lane source offsets inside a row of the pair tensor
     if (SEGM) {
       const int hs16 = o[3] >> 1;                // first pair of the segment = 16 hs
       const int blk = lane >> 4;                 // piece 1: block (hl = blk >> 1, parity = blk & 1), local slot lane & 15
@@ -447,21 +556,43 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       g17 = g17 >= HP ? g17 - HP : g17;
       lane_d2 = unsigned(((lane >> 1) & 1) * HB + (lane & 1) * PBK + g17 * 16);
     }
+    const unsigned s2 = unsigned(A.L[3]) * 32u, s1 = s2 * unsigned(A.L[2]), s0 = s1 * unsigned(A.L[1]);
+    unsigned c0[H0], c1[H1];
+#pragma unroll
+    for (int z = 0; z < H0; ++z) {
+      int x = o[0] + z - 1;
+      x = x < 0 ? x + A.L[0] : (x >= A.L[0] ? x - A.L[0] : x);
+      c0[z] = unsigned(x) * s0;
+    }
+#pragma unroll
+    for (int z = 0; z < H1; ++z) {
+      int x = o[1] + z - 1;
+      x = x < 0 ? x + A.L[1] : (x >= A.L[1] ? x - A.L[1] : x);
+      c1[z] = unsigned(x) * s1;
+    }
+#pragma unroll
+    for (int z = 0; z < H0 * H1; ++z) dma_ab[z] = base + (c0[z / H1] + c1[z % H1]);
+#pragma unroll
+    for (int z = 0; z < H2; ++z) {
+      int x = o[2] + z - 1;
+      x = x < 0 ? x + A.L[2] : (x >= A.L[2] ? x - A.L[2] : x);
+      dma_v[z] = lane_d + unsigned(x) * s2;
+      dma_v2[z] = lane_d2 + unsigned(x) * s2;
+    }
   };
   auto dma_rows = [&](unsigned buf, auto R0, auto R1) {     // halo rows [R0, R1) -> image buffer at LDS byte address buf
     constexpr int r0 = decltype(R0)::value, r1 = decltype(R1)::value;
 #pragma unroll
-    for (int i = r0; i < r1; ++i) {
-      const unsigned ro = unsigned(__builtin_amdgcn_readlane(dma_off, i));
-      const unsigned char *src = dma_src + uint64_t(ro) * 32u;
-      dma_row(src, lane_d, buf + unsigned(i * RBL));
-      if (SEGM) {
-        if (lane < 4) dma_row(src, lane_d2, buf + unsigned(i * RBL + 1024));
+    for (int i = r0; i < r1; ++i) dma_row(dma_ab[i / H2], dma_v[i % H2], buf + unsigned(i * RBL));
+    if (SEGM) {
+      if (lane < 4) {
+#pragma unroll
+        for (int i = r0; i < r1; ++i) dma_row(dma_ab[i / H2], dma_v2[i % H2], buf + unsigned(i * RBL + 1024));
       }
     }
   };
   typedef std::integral_constant<int, 0> I0;
-  typedef std::integral_constant<int, NROW / 2> IH;
+  typedef std::integral_constant<int, NF_H_DMA_EARLY> IH;     // rows issued before B1 (the rest behind it)
   typedef std::integral_constant<int, NROW> IN;
   if (pre) {                                    // image 0
     dma_open(cb, co4);
@@ -511,6 +642,7 @@ int conv_h_eligible(const ConvArgs &A, int fuse, int64_t *nboxes) {
     if (A.k[mu] != 3) return 0;
   if (A.L[3] < 32 || (A.L[3] & 15)) return 0;                // whole or half segments
   if (A.L[3] != 32 && !A.in_split16) return 0;               // fp32 planes are staged by the whole-row fallback only
+  if (A.in_split16 && A.V * 32 >= (int64_t(1) << 32)) return 0;       // the mover's row offsets inside a sample are 32-bit
   for (int mu = 0; mu < 3; ++mu)
     if (A.L[mu] < 2 || (A.L[mu] & 1)) return 0;             // even extents: whole boxes, row parity independent of the box
   if (nboxes) *nboxes = int64_t(A.L[0] / 2) * (A.L[1] / 2) * (A.L[2] / 2) * ((A.L[3] / 2 + 15) / 16);
