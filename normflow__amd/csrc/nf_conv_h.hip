@@ -603,11 +603,16 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   if (n_my > 1) advance(n1b, n1o);
   prefetch_x(cb, co4);
   lds_barrier();                                // P: image 0 ready
-  for (int m = 0; m < n_my; ++m) {
+  // n_my + 1 rounds, the last one only the epilogue of the last item: ONE copy of the epilogue in the code, so that every
+  // item's spline runs through the same instructions whatever its place in the workgroup's sequence.  (With a second,
+  // separately inlined copy behind the loop the compiler is free to contract a * b + c differently in the two, and the last
+  // bit of log|J| then depends on the batch order: seen in an experiment of round 2)
+  for (int m = 0; m <= n_my; ++m) {
     if (m > 0 && !NF_DBG(A, 128)) epilogue(pb, po, int64_t(vb) + int64_t(m - 1) * nb);     // dbg 128: timing ablation
+    if (m == n_my) break;
     prefetch_x(cb, co4);                        // for the epilogue of item m, one iteration from now
-    // image m+1 goes where image m-1 and then the partial sums of item m-1 were: after the epilogue above.  Half of its
-    // rows are issued here, half behind B1 (while the compute waves store and add: this wave has nothing else to do then)
+    // image m+1 goes where image m-1 and then the partial sums of item m-1 were: after the epilogue above, all rows ahead of
+    // B1 (they need the whole MFMA phase and the add-up behind it to land)
     const bool more = m + 1 < n_my && !NF_DBG(A, 64);          // dbg 64: timing ablation
     const unsigned nbuf = lds0m + unsigned(((m + 1) & 1) * ITEM);
     if (more) {
@@ -629,7 +634,6 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     if (pre) wait_vm<0>();                      // image m+1 has landed (a whole MFMA phase after its first row was issued)
     lds_barrier();                              // Bs: the compute waves have added them up: logits of item m in pt
   }
-  epilogue(pb, po, int64_t(vb) + int64_t(n_my - 1) * nb);
 }
 
 // Is this fused layer the split-fp16 kernel's, and with how many boxes per sample?  (The kernel has its own box: 2 x 2 x 2
