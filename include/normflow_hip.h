@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NF_VERSION 201 /* 0.2.0 */
+#define NF_VERSION 202 /* 0.2.0 */
 
 /* NF_F16 (nf_rqs_fwd / nf_rqs_inv with knots_len 4/8/16, nf_affine_fwd / nf_affine_inv): x, params and y are IEEE half, the arithmetic is fp32 and
  * log0 / logj are fp32 ("fp16 params / fp32 log-det accumulate", BASELINE config 5). */
@@ -376,6 +376,17 @@ int nf_act_vjp(const void *grad_out, const void *y, void *grad_pre, int64_t n, i
 int nf_conv_wgrad_cols(int cin, int ntaps);
 int nf_conv_wgrad(const void *in, const void *gz, void *gw, int64_t B, const int32_t *lattice,
                   const int32_t *ksize, int cin, int cout, int dtype, void *stream);
+
+/* The same weight gradient on the fp16 matrix cores (every fp32 product as three fp16 products, fp32 accumulation;
+ * gz scaled by a power of two measured in a first pass) for the lattice networks' shapes: 4-D lattice with 32 sites on
+ * the fastest axis, 3^4 kernels, cin 1 or 8, cout <= 48, fp32.  Same gw layout and accumulate-into-gw semantics as
+ * nf_conv_wgrad; deterministic (per-workgroup partial matrices in the workspace, summed in a fixed order).
+ * nf_conv_wgrad_split16_supported says whether a shape qualifies; callers fall back to nf_conv_wgrad otherwise. */
+int nf_conv_wgrad_split16_supported(const int32_t *lattice, const int32_t *ksize, int cin, int cout);
+size_t nf_conv_wgrad_split16_workspace(int64_t B, const int32_t *lattice, int cin);
+int nf_conv_wgrad_split16(const void *in, const void *gz, void *gw, int64_t B, const int32_t *lattice,
+                          const int32_t *ksize, int cin, int cout, void *workspace, size_t workspace_bytes,
+                          void *stream);
 
 #ifdef __cplusplus
 }

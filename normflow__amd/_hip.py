@@ -71,6 +71,9 @@ PROTOTYPES = {
     "nf_act_vjp": (_I, [_P, _P, _P, _I64, _I, _I, _P]),
     "nf_conv_wgrad_cols": (_I, [_I, _I]),
     "nf_conv_wgrad": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I, _P]),
+    "nf_conv_wgrad_split16_supported": (_I, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I]),
+    "nf_conv_wgrad_split16_workspace": (_SZ, [_I64, C.POINTER(C.c_int32), _I]),
+    "nf_conv_wgrad_split16": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _P, _SZ, _P]),
     "nf_conv_rqs_supported": (_I, [_I, _I]),
     "nf_conv_last_path": (_I, []),
     "nf_conv_split16_supported": (_I, [_P, _P, _I, _I, _I]),
@@ -770,10 +773,18 @@ def conv_weight_grad(x, gz, ksize):
         part = gz if (c0 == 0 and c1 == cout) else gz[:, c0:c1]
         part = part.contiguous()
         buf = torch.zeros(((c1 - c0 + 15) // 16) * 16, ncols, dtype=x.dtype, device=x.device)
+        split = (x.dtype == torch.float32 and lib.nf_get_option(OPT_SPLIT16)
+                 and lib.nf_conv_wgrad_split16_supported(lat4, k4, cin, c1 - c0))
         for b0 in range(0, B, MAX_B):
             b1 = min(B, b0 + MAX_B)
-            _check(lib.nf_conv_wgrad(_ptr(x[b0:b1]), _ptr(part[b0:b1]), _ptr(buf), b1 - b0, lat4, k4, cin,
-                                     c1 - c0, _dtype_code(x), _stream()), "nf_conv_wgrad")
+            if split:       # fp16 matrix cores, three products per fp32 product (nf_conv_w.hip)
+                need = lib.nf_conv_wgrad_split16_workspace(b1 - b0, lat4, cin)
+                ws = torch.empty(int(need), dtype=torch.uint8, device=x.device)
+                _check(lib.nf_conv_wgrad_split16(_ptr(x[b0:b1]), _ptr(part[b0:b1]), _ptr(buf), b1 - b0, lat4, k4, cin,
+                                                 c1 - c0, _ptr(ws), ws.numel(), _stream()), "nf_conv_wgrad_split16")
+            else:
+                _check(lib.nf_conv_wgrad(_ptr(x[b0:b1]), _ptr(part[b0:b1]), _ptr(buf), b1 - b0, lat4, k4, cin,
+                                         c1 - c0, _dtype_code(x), _stream()), "nf_conv_wgrad")
         gws.append(buf[:c1 - c0, :ntaps * cin])
         gbs.append(buf[:c1 - c0, ntaps * cin])
     gw = torch.cat(gws) if len(gws) > 1 else gws[0]

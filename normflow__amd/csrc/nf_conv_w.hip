@@ -1,0 +1,385 @@
+// nf_conv_w.hip -- weight gradient of a 3^4 circular conv layer on the fp16 matrix cores (gfx950), fp32 in and out.
+//
+//   gw[o][t cin + i] = sum_{b, n} gz[b, o, n] * in[b, i, (n + t - 1) mod L]      (t = the 81 taps, row-major)
+//   gw[o][81 cin]    = sum_{b, n} gz[b, o, n]                                       (bias)
+//
+// what autograd derives for ConvAct's layers in Fitter.step (reference: src/_normflowcore.py:275-294 differentiating
+// src/nn/scalar/modules.py:120-145).  A GEMM with the SITES as the reduction axis: M = cout (<= 48), N = 81 cin (+ 1),
+// K = B V.  The generic kernel (nf_conv.hip, conv_wgrad_kernel) feeds the fp32 MFMA from per-lane LDS gathers and runs at
+// ~38 TFLOP/s; this one is for the shapes of the lattice networks (4-D, 32 sites on the fastest axis, cin 1 or 8) and
+// computes every fp32 product as three fp16 products (a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32 accumulation), like the
+// forward chain (nf_conv_c/g/h.hip).
+//
+// One MFMA k-step (K = 32) = one lattice row: lane (column, kq) holds 8 consecutive sites 8 kq .. 8 kq + 7 of the row.
+//   A (gz):  lane (m = channel o, kq): 16 contiguous bytes of o's row image -- no shift.
+//   B (in):  column n = (kernel row c = (j0, j1, j2), input channel i); the tap j3 along the fastest axis shifts the 8 sites by
+//            j3 - 1: a lane reads the 24 bytes around its run once (sites 8 kq - 2 .. 8 kq + 9: one aligned 16-byte read and
+//            the two words beside it) and forms the three shifted fragments with v_alignbyte -- the three taps j3 share one
+//            read.  Row images carry one wrapped site on either side.
+// Work: a workgroup (7 multiplying waves + 1 staging wave) marches "columns" (sample, x0, x1) along axis 2, one lattice row
+// per step: the 3 x 3 neighbour rows of plane x2 + 2 are staged (fp32 -> (hi, lo) halfs) into a 4-plane LDS ring while
+// plane x2 is multiplied; gz's row is double-buffered.  Multiplying wave w owns column groups 2w, 2w + 1 (a group = two
+// kernel rows x 8 channels, or 16 kernel rows x 1 channel; x 3 taps j3) for all cout: 18 accumulator tiles, kept for the
+// whole launch; they leave as one partial (cout, 81 cin + 1) matrix per workgroup, summed in a fixed order by a second
+// kernel: deterministic, no atomics.
+// gz is scaled by a power of two that brings its largest magnitude to ~2^13 (cotangents of a mean over the batch are far
+// below fp16's normal range): one max-reduction pass over gz first.
+#include <hip/hip_fp16.h>
+#include "nf_conv_core.h"
+
+namespace nf {
+namespace wg {
+
+constexpr int kThreads = 512;                 // 7 multiplying waves + the stager
+constexpr int RS = 208;                       // bytes of a (row, channel) image: 48 hi halfs | 48 lo halfs | pad (conflict-free B reads)
+constexpr int LO = 96;                        // offset of the lo halfs in it; site x sits at half 8 + x, wrapped copies at 7 and 40
+constexpr int GS = 144;                       // bytes of a gz row image: 32 hi halfs | 32 lo halfs | pad
+constexpr int GLO = 64;
+constexpr int NSLOT = 4;                      // ring of x2 planes
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct Args {
+  const float *in, *gz;
+  float *partial;                             // (gridDim.x, 48, ncols)
+  const unsigned *absmax;                     // bits of max |gz|
+  int64_t V;
+  int L[4];
+  int B, cin, cout, ncols;
+  int64_t ncolumns;                           // B L0 L1
+};
+
+extern __shared__ __align__(16) unsigned char smem_w[];
+
+__device__ __forceinline__ float gz_scale(const unsigned *absmax) {
+  const float mx = __uint_as_float(*absmax);
+  if (!(mx > 0.f) || !(mx < 3.0e38f)) return 1.f;
+  int e;
+  (void)frexpf(mx, &e);                       // mx = f 2^e, f in [0.5, 1)
+  return ldexpf(1.f, 13 - e);                 // scaled maximum in [2^12, 2^13)
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ p, int64_t n, unsigned *out) {
+  float m = 0.f;
+  const int64_t n4 = n >> 2;
+  const float4 *p4 = reinterpret_cast<const float4 *>(p);
+  for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n4; i += int64_t(gridDim.x) * 256) {
+    const float4 v = p4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  for (int64_t i = (n4 << 2) + int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) m = fmaxf(m, fabsf(p[i]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bits
+}
+
+// fp32 -> (hi, lo) halfs of four values
+__device__ __forceinline__ void split4(const float4 v, f16x4 &hi, f16x4 &lo) {
+  const float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const _Float16 h = static_cast<_Float16>(a[r]);
+    hi[r] = h;
+    lo[r] = static_cast<_Float16>(a[r] - static_cast<float>(h));
+  }
+}
+
+template <int MT, int CIN>
+__global__ __launch_bounds__(kThreads, 2) void wgrad16_kernel(Args A) {
+  constexpr int PLANE = 9 * CIN * RS;           // one x2 plane of the ring: 3 x 3 neighbour rows x channels
+  constexpr int NG = CIN == 8 ? 14 : 2;         // column groups of 16: (2 kernel rows x 8 channels) or (16 kernel rows x 1)
+  unsigned char *ring = smem_w;
+  unsigned char *gbuf = smem_w + NSLOT * PLANE; // two gz row images of 48 channels
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 15, kq = lane >> 4;
+  const int L0 = A.L[0], L1 = A.L[1], L2 = A.L[2];
+  const int64_t rowsz = 32;                     // sites of a lattice row (the fastest axis)
+  const float scale = gz_scale(A.absmax);
+
+  // zero the gz images once: channels cout .. 47 are never written
+  for (int i = threadIdx.x; i < 2 * 48 * GS / 4; i += kThreads) reinterpret_cast<unsigned *>(gbuf)[i] = 0u;
+
+  // ---- multiplying waves: per-lane constants of their two groups
+  int boff[2] = {0, 0}, bj2[2] = {0, 0};
+  bool bvalid[2] = {false, false}, bones[2] = {false, false}, gact[2] = {false, false};
+  if (wave < 7) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int g = 2 * wave + q;
+      gact[q] = g < NG;
+      const int c = CIN == 8 ? 2 * g + (n >> 3) : 16 * g + n;       // kernel row (j0, j1, j2) of this lane's column
+      const int ci = CIN == 8 ? (n & 7) : 0;
+      bvalid[q] = gact[q] && c < 27;
+      bones[q] = gact[q] && c == 27 && ci == 0;                    // the bias column: B = 1
+      const int cc = c < 27 ? c : 26;
+      const int j0 = cc / 9, j1 = (cc / 3) % 3;
+      bj2[q] = cc % 3;
+      boff[q] = ((j0 * 3 + j1) * CIN + ci) * RS + 12 + 16 * kq;    // word 0 of the lane's 24 bytes (sites 8 kq - 2 ..)
+    }
+  }
+  f32x4 acc[MT][2][3];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) acc[mi][q][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- the stager's view: lane -> (channel, quad of sites) of a row
+  auto site_row = [&](int x0, int x1, int x2) {         // first site of lattice row (x0, x1, x2), coordinates wrapped
+    x0 = x0 < 0 ? x0 + L0 : (x0 >= L0 ? x0 - L0 : x0);
+    x1 = x1 < 0 ? x1 + L1 : (x1 >= L1 ? x1 - L1 : x1);
+    x2 = x2 < 0 ? x2 + L2 : (x2 >= L2 ? x2 - L2 : x2);
+    return ((int64_t(x0) * L1 + x1) * L2 + x2) * rowsz;
+  };
+  auto put_row = [&](unsigned char *img, int q4, const float4 v) {       // sites 4 q4 .. 4 q4 + 3 of a row image, with the wrapped copies
+    f16x4 hi, lo;
+    split4(v, hi, lo);
+    *reinterpret_cast<f16x4 *>(img + (8 + 4 * q4) * 2) = hi;
+    *reinterpret_cast<f16x4 *>(img + LO + (8 + 4 * q4) * 2) = lo;
+    if (q4 == 0) {
+      *reinterpret_cast<_Float16 *>(img + 40 * 2) = hi[0];
+      *reinterpret_cast<_Float16 *>(img + LO + 40 * 2) = lo[0];
+    }
+    if (q4 == 7) {
+      *reinterpret_cast<_Float16 *>(img + 7 * 2) = hi[3];
+      *reinterpret_cast<_Float16 *>(img + LO + 7 * 2) = lo[3];
+    }
+  };
+  auto stage_plane = [&](int b, int x0, int x1, int lx2) {      // logical plane lx2 (-1 .. L2) of column (b, x0, x1) -> ring slot
+    unsigned char *pl = ring + ((lx2 + NSLOT) & (NSLOT - 1)) * PLANE;
+    const float *src = A.in + int64_t(b) * CIN * A.V;
+    if (CIN == 8) {
+      const int ci = lane >> 3, q4 = lane & 7;
+      float4 v[9];
+#pragma unroll
+      for (int rs = 0; rs < 9; ++rs)
+        v[rs] = *reinterpret_cast<const float4 *>(src + int64_t(ci) * A.V + site_row(x0 + rs / 3 - 1, x1 + rs % 3 - 1, lx2) + 4 * q4);
+#pragma unroll
+      for (int rs = 0; rs < 9; ++rs) put_row(pl + (rs * CIN + ci) * RS, q4, v[rs]);
+    } else {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int f = lane + 64 * it;
+        if (f < 72) {
+          const int rs = f >> 3, q4 = f & 7;
+          const float4 v = *reinterpret_cast<const float4 *>(src + site_row(x0 + rs / 3 - 1, x1 + rs % 3 - 1, lx2) + 4 * q4);
+          put_row(pl + rs * RS, q4, v);
+        }
+      }
+    }
+  };
+  auto stage_gz = [&](int b, int x0, int x1, int x2, int buf) {
+    const float *src = A.gz + int64_t(b) * A.cout * A.V + site_row(x0, x1, x2);
+    unsigned char *gb = gbuf + buf * 48 * GS;
+    constexpr int NIT = (16 * MT * 8 + 63) / 64;
+    float4 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int f = lane + 64 * it, co = f >> 3, q4 = f & 7;
+      v[it] = co < A.cout ? *reinterpret_cast<const float4 *>(src + int64_t(co) * A.V + 4 * q4) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int f = lane + 64 * it, co = f >> 3, q4 = f & 7;
+      if (co < A.cout) {
+        float4 s = v[it];
+        s.x *= scale; s.y *= scale; s.z *= scale; s.w *= scale;
+        f16x4 hi, lo;
+        split4(s, hi, lo);
+        *reinterpret_cast<f16x4 *>(gb + co * GS + 8 * q4) = hi;
+        *reinterpret_cast<f16x4 *>(gb + co * GS + GLO + 8 * q4) = lo;
+      }
+    }
+  };
+
+  // ---- one lattice row: 3 x MT x (2 groups x 3 taps) MFMAs per multiplying wave
+  auto multiply = [&](int t) {
+    const unsigned char *gb = gbuf + (t & 1) * 48 * GS;
+    f16x8 ah[MT], al[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const unsigned char *pa = gb + (16 * mi + n) * GS + 16 * kq;
+      ah[mi] = *reinterpret_cast<const f16x8 *>(pa);
+      al[mi] = *reinterpret_cast<const f16x8 *>(pa + GLO);
+    }
+    int slot[3];
+#pragma unroll
+    for (int j2 = 0; j2 < 3; ++j2) slot[j2] = ((t + j2 - 1 + NSLOT) & (NSLOT - 1)) * PLANE;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (!gact[q]) continue;                   // (wave-uniform)
+      const unsigned char *pb = ring + (bj2[q] == 0 ? slot[0] : (bj2[q] == 1 ? slot[1] : slot[2])) + boff[q];
+      unsigned wh[6], wl[6];
+      wh[0] = *reinterpret_cast<const unsigned *>(pb);
+      wl[0] = *reinterpret_cast<const unsigned *>(pb + LO);
+      const u32x4 mh = *reinterpret_cast<const u32x4 *>(pb + 4), ml = *reinterpret_cast<const u32x4 *>(pb + LO + 4);
+      wh[5] = *reinterpret_cast<const unsigned *>(pb + 20);
+      wl[5] = *reinterpret_cast<const unsigned *>(pb + LO + 20);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { wh[1 + r] = mh[r]; wl[1 + r] = ml[r]; }
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {             // tap j3 = s: sites shifted by s - 1
+        u32x4 fh, fl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (s == 1) { fh[r] = wh[1 + r]; fl[r] = wl[1 + r]; }
+          else if (s == 0) { fh[r] = __builtin_amdgcn_alignbyte(wh[1 + r], wh[r], 2); fl[r] = __builtin_amdgcn_alignbyte(wl[1 + r], wl[r], 2); }
+          else { fh[r] = __builtin_amdgcn_alignbyte(wh[2 + r], wh[1 + r], 2); fl[r] = __builtin_amdgcn_alignbyte(wl[2 + r], wl[1 + r], 2); }
+        }
+        if (!bvalid[q]) {                       // columns past the 27 kernel rows: zero, or the bias column's ones (tap 1 only)
+          const unsigned one = (bones[q] && s == 1) ? 0x3c003c00u : 0u;
+          fh = u32x4{one, one, one, one};
+          fl = u32x4{0u, 0u, 0u, 0u};
+        }
+        const f16x8 bh = __builtin_bit_cast(f16x8, fh), bl = __builtin_bit_cast(f16x8, fl);
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          acc[mi][q][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bh, acc[mi][q][s], 0, 0, 0);
+          acc[mi][q][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bl, acc[mi][q][s], 0, 0, 0);
+          acc[mi][q][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mi], bh, acc[mi][q][s], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  __syncthreads();
+  for (int64_t col = blockIdx.x; col < A.ncolumns; col += gridDim.x) {
+    const int b = int(col / (int64_t(L0) * L1));
+    const int rem = int(col - int64_t(b) * L0 * L1);
+    const int x0 = rem / L1, x1 = rem - x0 * L1;
+    if (wave == 7) {                              // planes -1, 0, 1 and gz's first row
+      stage_plane(b, x0, x1, -1);
+      stage_plane(b, x0, x1, 0);
+      stage_plane(b, x0, x1, 1);
+      stage_gz(b, x0, x1, 0, 0);
+    }
+    __syncthreads();
+    for (int t = 0; t < L2; ++t) {
+      if (wave == 7) {
+        if (t + 1 < L2) {
+          stage_plane(b, x0, x1, t + 2);
+          stage_gz(b, x0, x1, t + 1, (t + 1) & 1);
+        }
+      } else {
+        multiply(t);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- this workgroup's partial matrix: D[m][n] of tile (mi, group, tap): lane (n, g4) holds rows 4 g4 .. 4 g4 + 3
+  if (wave < 7) {
+    float *out = A.partial + int64_t(blockIdx.x) * 48 * A.ncols;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (!gact[q]) continue;
+      const int g = 2 * wave + q;
+      const int c = CIN == 8 ? 2 * g + (n >> 3) : 16 * g + n;
+      const int ci = CIN == 8 ? (n & 7) : 0;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        int colx = -1;
+        if (c < 27) colx = (c * 3 + s) * CIN + ci;
+        else if (c == 27 && ci == 0 && s == 1) colx = 81 * CIN;
+        if (colx < 0) continue;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) out[int64_t(16 * mi + 4 * kq + r) * A.ncols + colx] = acc[mi][q][s][r];
+      }
+    }
+  }
+}
+
+// gw[o][c] += (sum over the workgroups' partials, in order) / scale
+__global__ __launch_bounds__(256) void wgrad16_reduce_kernel(const float *__restrict__ partial, float *__restrict__ gw, int nparts, int ncols,
+                                                             int nused, int rows, const unsigned *absmax) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * nused) return;
+  const int o = idx / nused, c = idx - o * nused;
+  double s = 0.0;
+  for (int p = 0; p < nparts; ++p) s += double(partial[(int64_t(p) * 48 + o) * ncols + c]);
+  gw[int64_t(o) * ncols + c] += float(s / double(gz_scale(absmax)));
+}
+
+}  // namespace wg
+}  // namespace nf
+
+using namespace nf;
+
+extern "C" int nf_conv_wgrad_cols(int cin, int ntaps);
+
+extern "C" int nf_conv_wgrad_split16_supported(const int32_t *lattice, const int32_t *ksize, int cin, int cout) {
+  if (!lattice || !ksize) return 0;
+  for (int mu = 0; mu < 4; ++mu)
+    if (ksize[mu] != 3 || lattice[mu] < 1) return 0;
+  if (lattice[3] != 32) return 0;
+  if (cin != 1 && cin != 8) return 0;
+  return cout >= 1 && cout <= 48;
+}
+
+static int wgrad16_grid(int64_t ncolumns) { return int(ncolumns < 512 ? ncolumns : 512); }
+
+extern "C" size_t nf_conv_wgrad_split16_workspace(int64_t B, const int32_t *lattice, int cin) {
+  if (!lattice) return 0;
+  const int64_t ncolumns = B * lattice[0] * lattice[1];
+  return 256 + size_t(wgrad16_grid(ncolumns)) * 48 * size_t(nf_conv_wgrad_cols(cin, 81)) * sizeof(float);
+}
+
+extern "C" int nf_conv_wgrad_split16(const void *in, const void *gz, void *gw, int64_t B, const int32_t *lattice,
+                                     const int32_t *ksize, int cin, int cout, void *workspace, size_t workspace_bytes,
+                                     void *stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  NF_REQUIRE(in && gz && gw && lattice && ksize, "nf_conv_wgrad_split16: NULL pointer");
+  NF_REQUIRE(nf_conv_wgrad_split16_supported(lattice, ksize, cin, cout),
+             "nf_conv_wgrad_split16: needs a 4-D lattice with 32 sites on the fastest axis, 3^4 kernels, cin 1 or 8, cout <= 48");
+  NF_REQUIRE(B >= 0 && B < (int64_t(1) << 24), "nf_conv_wgrad_split16: bad batch");
+  if (B == 0) return NF_OK;
+  wg::Args A{};
+  A.V = 1;
+  for (int mu = 0; mu < 4; ++mu) { A.L[mu] = lattice[mu]; A.V *= lattice[mu]; }
+  NF_REQUIRE(A.V < (int64_t(1) << 31), "nf_conv_wgrad_split16: lattice volume must be < 2^31");
+  A.in = static_cast<const float *>(in);
+  A.gz = static_cast<const float *>(gz);
+  A.B = int(B); A.cin = cin; A.cout = cout;
+  A.ncols = nf_conv_wgrad_cols(cin, 81);
+  A.ncolumns = B * A.L[0] * A.L[1];
+  const int grid = wgrad16_grid(A.ncolumns);
+  const size_t need = nf_conv_wgrad_split16_workspace(B, lattice, cin);
+  if (!workspace || workspace_bytes < need) {
+    set_error("nf_conv_wgrad_split16: workspace %zu B < %zu B needed", workspace_bytes, need);
+    return NF_EWORKSPACE;
+  }
+  unsigned *absmax = static_cast<unsigned *>(workspace);
+  A.absmax = absmax;
+  A.partial = reinterpret_cast<float *>(static_cast<unsigned char *>(workspace) + 256);
+  NF_REQUIRE(hipMemsetAsync(workspace, 0, need, s) == hipSuccess, "nf_conv_wgrad_split16: hipMemsetAsync failed");
+  const int64_t ngz = B * cout * A.V;
+  hipLaunchKernelGGL(wg::absmax_kernel, dim3(2048), dim3(256), 0, s, A.gz, ngz, absmax);
+  int rc = check_launch("wgrad absmax kernel");
+  if (rc) return rc;
+  const int MT = (cout + 15) >> 4;
+  const size_t lds = size_t(wg::NSLOT) * 9 * cin * wg::RS + 2 * 48 * wg::GS;
+#define NF_W16(MTV, CINV)                                                                                              \
+  {                                                                                                                    \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wg::wgrad16_kernel<MTV, CINV>),                          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));                                  \
+    hipLaunchKernelGGL((wg::wgrad16_kernel<MTV, CINV>), dim3(grid), dim3(wg::kThreads), lds, s, A);                    \
+  }
+  if (cin == 8) {
+    if (MT == 1) NF_W16(1, 8) else if (MT == 2) NF_W16(2, 8) else NF_W16(3, 8)
+  } else {
+    if (MT == 1) NF_W16(1, 1) else if (MT == 2) NF_W16(2, 1) else NF_W16(3, 1)
+  }
+#undef NF_W16
+  rc = check_launch("wgrad16 kernel");
+  if (rc) return rc;
+  const int nused = 81 * cin + 1;
+  const int total = cout * nused;
+  hipLaunchKernelGGL(wg::wgrad16_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, A.partial,
+                     static_cast<float *>(gw), grid, A.ncols, nused, cout, absmax);
+  return check_launch("wgrad16 reduce kernel");
+}

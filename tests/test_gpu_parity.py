@@ -1632,3 +1632,32 @@ def test_hack_and_propagate_density(dtype):
             cpl(x.clone().requires_grad_(True))
         finally:
             cpl.propagate_density = False
+
+
+@pytest.mark.parametrize("lattice,cin,cout,B", [((2, 3, 4, 32), 8, 46, 3), ((2, 2, 2, 32), 1, 8, 5), ((4, 2, 2, 32), 8, 8, 2),
+                                                ((1, 1, 3, 32), 8, 22, 4), ((3, 2, 1, 32), 1, 8, 2)])
+def test_conv_wgrad_split16_kernel_vs_autograd(lattice, cin, cout, B):
+    """nf_conv_wgrad_split16 (nf_conv_w.hip): grad_weight and grad_bias of a 3^4 circular conv layer on the fp16 matrix cores
+    (three fp16 products per fp32 product, gz scaled into fp16's range) against autograd through the fp64 oracle
+    convolution, with cotangents of the magnitude a mean over a batch produces (1e-6) as well as O(1); equal to the fp32
+    kernel (nf_conv_wgrad) within the same bound; deterministic.  2e-5 relative to the largest entry, the fp32 kernel's
+    bound in test_conv_vjp_kernels_vs_autograd."""
+    g = torch.Generator(device='cpu').manual_seed(cin * 100 + cout)
+    x = torch.randn((B, cin) + lattice, generator=g, dtype=torch.float64, device='cpu')
+    w = 0.3 * torch.randn((cout, cin) + (3,) * 4, generator=g, dtype=torch.float64, device='cpu')
+    bias = torch.randn(cout, generator=g, dtype=torch.float64, device='cpu')
+    for gscale in (1.0, 1e-6):
+        go = gscale * torch.randn((B, cout) + lattice, generator=g, dtype=torch.float64, device='cpu')
+        go[:, :, 0, 0, 0, :4] *= 50.0                    # a few large entries: the scale follows the maximum
+        wo, bo = w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+        ref = O.circular_conv_direct(x, wo, bo)
+        gw_ref, gb_ref = torch.autograd.grad(ref, (wo, bo), go)
+        xd, god = x.to(DEV, torch.float32), go.to(DEV, torch.float32)
+        assert _hip.load().nf_conv_wgrad_split16_supported(*_hip._lat4(lattice, (3,) * 4), cin, cout)
+        gw, gb = _hip.conv_weight_grad(xd, god, (3,) * 4)
+        gw2, gb2 = _hip.conv_weight_grad(xd, god, (3,) * 4)
+        assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+        with _hip.options(split16=False):
+            gw32, gb32 = _hip.conv_weight_grad(xd, god, (3,) * 4)
+        for got, want in ((gw, gw_ref), (gb, gb_ref), (gw32, gw_ref), (gb32, gb_ref)):
+            assert float((got.double().cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
