@@ -382,6 +382,10 @@ int nf_conv_wgrad(const void *in, const void *gz, void *gw, int64_t B, const int
  * the fastest axis, 3^4 kernels, cin 1 or 8, cout <= 48, fp32.  Same gw layout and accumulate-into-gw semantics as
  * nf_conv_wgrad; deterministic (per-workgroup partial matrices in the workspace, summed in a fixed order).
  * nf_conv_wgrad_split16_supported says whether a shape qualifies; callers fall back to nf_conv_wgrad otherwise. */
+/* nf_expand_pairs: a pair-compact tensor (rows, V/2) -- the layout the active-site-only conv output and its cotangent use --
+ * to the full lattice (rows, V), zeros at the sites of the other parity; rows = B * channels; lattice[3] even. */
+int nf_expand_pairs(const void *compact, void *full, int64_t rows, const int32_t *lattice, int parity, int dtype,
+                    void *stream);
 int nf_conv_wgrad_split16_supported(const int32_t *lattice, const int32_t *ksize, int cin, int cout);
 size_t nf_conv_wgrad_split16_workspace(int64_t B, const int32_t *lattice, int cin);
 int nf_conv_wgrad_split16(const void *in, const void *gz, void *gw, int64_t B, const int32_t *lattice,

@@ -71,6 +71,7 @@ PROTOTYPES = {
     "nf_act_vjp": (_I, [_P, _P, _P, _I64, _I, _I, _P]),
     "nf_conv_wgrad_cols": (_I, [_I, _I]),
     "nf_conv_wgrad": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I, _P]),
+    "nf_expand_pairs": (_I, [_P, _P, _I64, C.POINTER(C.c_int32), _I, _I, _P]),
     "nf_conv_wgrad_split16_supported": (_I, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I]),
     "nf_conv_wgrad_split16_workspace": (_SZ, [_I64, C.POINTER(C.c_int32), _I]),
     "nf_conv_wgrad_split16": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _P, _SZ, _P]),
@@ -737,18 +738,16 @@ def _conv_launch(x, weight, bias, act, compact, parity):
 
 
 def _compact_to_full(t, lattice, parity):
-    """(B, C, V/2) pair-compact -> (B, C, *L) with zeros at the other sites (host-side helper
-    of the conv VJP; the checkerboard is rebuilt from the coordinate sum)."""
+    """(B, C, V/2) pair-compact -> (B, C, *L) with zeros at the other sites (nf_expand_pairs: the checkerboard is
+    rebuilt from the coordinate sum)."""
+    _require_device(t)
     B, Cc, Vh = t.shape
-    total = torch.zeros(tuple(lattice), dtype=torch.int64, device=t.device)
-    for mu, n in enumerate(lattice):
-        view = [1] * len(lattice)
-        view[mu] = n
-        total = total + torch.arange(n, device=t.device).reshape(view)
-    first = ((total.reshape(-1, 2)[:, 0] % 2) == parity)
-    z = torch.zeros_like(t)
-    full = torch.stack((torch.where(first, t, z), torch.where(first, z, t)), dim=-1)
-    return full.reshape(B, Cc, *lattice)
+    t = t.contiguous()
+    full = torch.empty((B, Cc) + tuple(lattice), dtype=t.dtype, device=t.device)
+    lat4 = (C.c_int32 * 4)(*([1] * (4 - len(lattice)) + list(lattice)))
+    _check(load().nf_expand_pairs(_ptr(t), _ptr(full), B * Cc, lat4, int(parity), _dtype_code(t), _stream()),
+           "nf_expand_pairs")
+    return full
 
 
 def _lat4(lat, ksize):

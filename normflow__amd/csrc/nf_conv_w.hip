@@ -294,6 +294,26 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad16_kernel(Args A) {
   }
 }
 
+// pair-compact (rows, V/2) -> full (rows, V): the value of pair p of a lattice row goes to its active site (coordinate sum
+// == parity mod 2), the other site of the pair gets 0.  One pass (the host-side version was five).
+template <typename T, typename T2>
+__global__ __launch_bounds__(256) void expand_pairs_kernel(const T *__restrict__ src, T2 *__restrict__ dst, int64_t rows, int64_t Vh,
+                                                           int L0, int L1, int L2, int HP, int parity) {
+  const int64_t total = rows * Vh;
+  for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < total; i += int64_t(gridDim.x) * 256) {
+    const int64_t pr = i % Vh;                 // pair index inside the sample's lattice
+    const int64_t row = pr / HP;               // lattice row (x0, x1, x2)
+    const int x2 = int(row % L2), x1 = int((row / L2) % L1), x0 = int(row / (int64_t(L2) * L1));
+    const int first = ((x0 + x1 + x2) & 1) == parity;      // the pair's even site is the active one
+    const T v = src[i];
+    T2 o;
+    o.x = first ? v : T(0);
+    o.y = first ? T(0) : v;
+    dst[i] = o;
+  }
+  (void)L0;
+}
+
 // gw[o][c] += (sum over the workgroups' partials, in order) / scale
 __global__ __launch_bounds__(256) void wgrad16_reduce_kernel(const float *__restrict__ partial, float *__restrict__ gw, int nparts, int ncols,
                                                              int nused, int rows, const unsigned *absmax) {
@@ -382,4 +402,27 @@ extern "C" int nf_conv_wgrad_split16(const void *in, const void *gz, void *gw, i
   hipLaunchKernelGGL(wg::wgrad16_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, A.partial,
                      static_cast<float *>(gw), grid, A.ncols, nused, cout, absmax);
   return check_launch("wgrad16 reduce kernel");
+}
+
+extern "C" int nf_expand_pairs(const void *compact, void *full, int64_t rows, const int32_t *lattice, int parity, int dtype,
+                               void *stream) {
+  NF_REQUIRE(compact && full && lattice, "nf_expand_pairs: NULL pointer");
+  NF_REQUIRE(rows >= 0 && (parity == 0 || parity == 1), "nf_expand_pairs: bad arguments");
+  NF_REQUIRE(lattice[3] >= 2 && (lattice[3] & 1) == 0, "nf_expand_pairs: the fastest axis must be even");
+  const int64_t Vh = int64_t(lattice[0]) * lattice[1] * lattice[2] * (lattice[3] / 2);
+  if (rows == 0 || Vh == 0) return NF_OK;
+  const int64_t want = (rows * Vh + 255) / 256;
+  const unsigned grid = unsigned(want < 16384 ? want : 16384);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == NF_F32)
+    hipLaunchKernelGGL((wg::expand_pairs_kernel<float, float2>), dim3(grid), dim3(256), 0, s, static_cast<const float *>(compact),
+                       static_cast<float2 *>(full), rows, Vh, lattice[0], lattice[1], lattice[2], lattice[3] / 2, parity);
+  else if (dtype == NF_F64)
+    hipLaunchKernelGGL((wg::expand_pairs_kernel<double, double2>), dim3(grid), dim3(256), 0, s, static_cast<const double *>(compact),
+                       static_cast<double2 *>(full), rows, Vh, lattice[0], lattice[1], lattice[2], lattice[3] / 2, parity);
+  else {
+    set_error("nf_expand_pairs: unsupported dtype %d", dtype);
+    return NF_EINVAL;
+  }
+  return check_launch("expand pairs kernel");
 }
