@@ -86,7 +86,7 @@ __device__ __forceinline__ void split4(const float4 v, f16x4 &hi, f16x4 &lo) {
 }
 
 template <int MT, int CIN>
-__global__ __launch_bounds__(kThreads, 2) void wgrad16_kernel(Args A) {
+__global__ __launch_bounds__(kThreads, 4) void wgrad16_kernel(Args A) {
   constexpr int PLANE = 9 * CIN * RS;           // one x2 plane of the ring: 3 x 3 neighbour rows x channels
   constexpr int NG = CIN == 8 ? 14 : 2;         // column groups of 16: (2 kernel rows x 8 channels) or (16 kernel rows x 1)
   unsigned char *ring = smem_w;
@@ -148,44 +148,57 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad16_kernel(Args A) {
       *reinterpret_cast<_Float16 *>(img + LO + 7 * 2) = lo[3];
     }
   };
-  auto stage_plane = [&](int b, int x0, int x1, int lx2) {      // logical plane lx2 (-1 .. L2) of column (b, x0, x1) -> ring slot
-    unsigned char *pl = ring + ((lx2 + NSLOT) & (NSLOT - 1)) * PLANE;
+  // A plane / a gz row travel in two steps, global -> registers and registers -> LDS images, so that the stager can have the
+  // loads of step t + 1 in flight while the multiplying waves are still on step t (one round trip to memory per lattice
+  // row, taken in line, was most of the kernel's time).
+  constexpr int NPV = CIN == 8 ? 9 : 2;         // float4 per lane of a plane
+  constexpr int NGV = (16 * MT * 8 + 63) / 64;  // ... of a gz row
+  struct Staged { float4 pv[NPV]; float4 gv[NGV]; };
+  auto load_plane = [&](Staged &S, int b, int x0, int x1, int lx2) {      // logical plane lx2 (-1 .. L2) of column (b, x0, x1)
     const float *src = A.in + int64_t(b) * CIN * A.V;
     if (CIN == 8) {
       const int ci = lane >> 3, q4 = lane & 7;
-      float4 v[9];
 #pragma unroll
       for (int rs = 0; rs < 9; ++rs)
-        v[rs] = *reinterpret_cast<const float4 *>(src + int64_t(ci) * A.V + site_row(x0 + rs / 3 - 1, x1 + rs % 3 - 1, lx2) + 4 * q4);
-#pragma unroll
-      for (int rs = 0; rs < 9; ++rs) put_row(pl + (rs * CIN + ci) * RS, q4, v[rs]);
+        S.pv[rs] = *reinterpret_cast<const float4 *>(src + int64_t(ci) * A.V + site_row(x0 + rs / 3 - 1, x1 + rs % 3 - 1, lx2) + 4 * q4);
     } else {
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
-        const int f = lane + 64 * it;
-        if (f < 72) {
-          const int rs = f >> 3, q4 = f & 7;
-          const float4 v = *reinterpret_cast<const float4 *>(src + site_row(x0 + rs / 3 - 1, x1 + rs % 3 - 1, lx2) + 4 * q4);
-          put_row(pl + rs * RS, q4, v);
-        }
+        const int f = lane + 64 * it, rs = f >> 3, q4 = f & 7;
+        S.pv[it] = f < 72 ? *reinterpret_cast<const float4 *>(src + site_row(x0 + rs / 3 - 1, x1 + rs % 3 - 1, lx2) + 4 * q4)
+                          : float4{0.f, 0.f, 0.f, 0.f};
       }
     }
   };
-  auto stage_gz = [&](int b, int x0, int x1, int x2, int buf) {
-    const float *src = A.gz + int64_t(b) * A.cout * A.V + site_row(x0, x1, x2);
-    unsigned char *gb = gbuf + buf * 48 * GS;
-    constexpr int NIT = (16 * MT * 8 + 63) / 64;
-    float4 v[NIT];
+  auto commit_plane = [&](const Staged &S, int lx2) {            // -> ring slot of logical plane lx2
+    unsigned char *pl = ring + ((lx2 + NSLOT) & (NSLOT - 1)) * PLANE;
+    if (CIN == 8) {
+      const int ci = lane >> 3, q4 = lane & 7;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int f = lane + 64 * it, co = f >> 3, q4 = f & 7;
-      v[it] = co < A.cout ? *reinterpret_cast<const float4 *>(src + int64_t(co) * A.V + 4 * q4) : float4{0.f, 0.f, 0.f, 0.f};
+      for (int rs = 0; rs < 9; ++rs) put_row(pl + (rs * CIN + ci) * RS, q4, S.pv[rs]);
+    } else {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int f = lane + 64 * it, rs = f >> 3, q4 = f & 7;
+        if (f < 72) put_row(pl + rs * RS, q4, S.pv[it]);
+      }
     }
+  };
+  auto load_gz = [&](Staged &S, int b, int x0, int x1, int x2) {
+    const float *src = A.gz + int64_t(b) * A.cout * A.V + site_row(x0, x1, x2);
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
+    for (int it = 0; it < NGV; ++it) {
+      const int f = lane + 64 * it, co = f >> 3, q4 = f & 7;
+      S.gv[it] = co < A.cout ? *reinterpret_cast<const float4 *>(src + int64_t(co) * A.V + 4 * q4) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto commit_gz = [&](const Staged &S, int buf) {
+    unsigned char *gb = gbuf + buf * 48 * GS;
+#pragma unroll
+    for (int it = 0; it < NGV; ++it) {
       const int f = lane + 64 * it, co = f >> 3, q4 = f & 7;
       if (co < A.cout) {
-        float4 s = v[it];
+        float4 s = S.gv[it];
         s.x *= scale; s.y *= scale; s.z *= scale; s.w *= scale;
         f16x4 hi, lo;
         split4(s, hi, lo);
@@ -246,32 +259,56 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad16_kernel(Args A) {
   };
 
   __syncthreads();
-  for (int64_t col = blockIdx.x; col < A.ncolumns; col += gridDim.x) {
-    const int b = int(col / (int64_t(L0) * L1));
+  auto column_of = [&](int64_t col, int &b, int &x0, int &x1) {
+    b = int(col / (int64_t(L0) * L1));
     const int rem = int(col - int64_t(b) * L0 * L1);
-    const int x0 = rem / L1, x1 = rem - x0 * L1;
-    if (wave == 7) {                              // planes -1, 0, 1 and gz's first row
-      stage_plane(b, x0, x1, -1);
-      stage_plane(b, x0, x1, 0);
-      stage_plane(b, x0, x1, 1);
-      stage_gz(b, x0, x1, 0, 0);
-    }
-    __syncthreads();
-    for (int t = 0; t < L2; ++t) {
-      if (wave == 7) {
-        if (t + 1 < L2) {
-          stage_plane(b, x0, x1, t + 2);
-          stage_gz(b, x0, x1, t + 1, (t + 1) & 1);
-        }
-      } else {
-        multiply(t);
+    x0 = rem / L1;
+    x1 = rem - x0 * L1;
+  };
+  // Two loops with the same barriers, one per role: in one loop the stager's registers would be live across the other waves'
+  // MFMA code (the register allocator does not know that `wave` never changes), 98 of them spilled.
+  if (wave == 7) {
+    Staged S;
+    for (int64_t col = blockIdx.x; col < A.ncolumns; col += gridDim.x) {
+      int b, x0, x1;
+      column_of(col, b, x0, x1);
+      // planes -1, 0, 1 and gz's first row; plane 2 and the second row set off
+#pragma unroll 1
+      for (int lx2 = -1; lx2 <= 1; ++lx2) {
+        load_plane(S, b, x0, x1, lx2);
+        commit_plane(S, lx2);
       }
-      __syncthreads();
+      load_gz(S, b, x0, x1, 0);
+      commit_gz(S, 0);
+      if (L2 > 1) {
+        load_plane(S, b, x0, x1, 2);
+        load_gz(S, b, x0, x1, 1);
+      }
+      lds_barrier();
+      for (int t = 0; t < L2; ++t) {
+        if (t + 1 < L2) {                         // what was loaded a step ago: plane t + 2, gz row t + 1
+          commit_plane(S, t + 2);
+          commit_gz(S, (t + 1) & 1);
+        }
+        if (t + 2 < L2) {                         // lands while the others multiply row t
+          load_plane(S, b, x0, x1, t + 3);
+          load_gz(S, b, x0, x1, t + 2);
+        }
+        lds_barrier();                            // (LDS only: the loads stay in flight across it)
+      }
+    }
+    return;
+  }
+  for (int64_t col = blockIdx.x; col < A.ncolumns; col += gridDim.x) {
+    lds_barrier();
+    for (int t = 0; t < L2; ++t) {
+      multiply(t);
+      lds_barrier();
     }
   }
 
   // ---- this workgroup's partial matrix: D[m][n] of tile (mi, group, tap): lane (n, g4) holds rows 4 g4 .. 4 g4 + 3
-  if (wave < 7) {
+  {
     float *out = A.partial + int64_t(blockIdx.x) * 48 * A.ncols;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
