@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NF_VERSION 202 /* 0.2.0 */
+#define NF_VERSION 203 /* 0.2.0 */
 
 /* NF_F16 (nf_rqs_fwd / nf_rqs_inv with knots_len 4/8/16, nf_affine_fwd / nf_affine_inv): x, params and y are IEEE half, the arithmetic is fp32 and
  * log0 / logj are fp32 ("fp16 params / fp32 log-det accumulate", BASELINE config 5). */
@@ -138,6 +138,13 @@ int nf_rqs_inv_vjp(const void *x, const void *params, const uint8_t *mask,
                    const void *grad_out, const void *grad_logj, void *grad_in,
                    void *grad_params, int64_t B, int64_t V, const nf_rqs_opts *opts,
                    const nf_strides *strides, int dtype, void *stream);
+
+/* nf_affine_sites: nf_affine_fwd (inverse = 0) / nf_affine_inv (1) that additionally writes the log-derivative of every
+ * site (-|s| forward, +|s| inverse; 0 for a shift layer and at frozen sites) to site_out (B,V) of dtype: what
+ * Module_.sum_density passes through when propagate_density is set (src/nn/_core.py:19,38-42).  NF_F32 / NF_F64. */
+int nf_affine_sites(const void *v, const void *params, const uint8_t *mask, const void *log0, void *out,
+                    void *logj, void *site_out, int64_t B, int64_t V, int n_ch, int layout, int inverse,
+                    void *workspace, size_t workspace_bytes, int dtype, void *stream);
 
 /* ---- K2s: the spline object of a coupling layer -------------------------------
  * What a user of the reference reaches through RQSplineCoupling_.make_spline / _hack

@@ -56,6 +56,7 @@ PROTOTYPES = {
     "nf_rqs_inv_vjp": (_I, _VJP_ARGS),
     "nf_affine_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _P, _SZ, _I, _P]),
     "nf_affine_inv": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _P, _SZ, _I, _P]),
+    "nf_affine_sites": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _I, _P, _SZ, _I, _P]),
     "nf_affine_vjp": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _I, _I, _P]),
     "nf_distconv": (_I, [_P, _P, _I, _P, _P, _P, _I64, _I64, _I, _I, _P, _SZ, _I, _P]),
     "nf_distconv_vjp": (_I, [_P, _P, _I, _P, _P, _P, _P, _I64, _I64, _I, _I, _P, _SZ, _I, _P]),
@@ -373,6 +374,26 @@ class MultiRQSCouplingFn(torch.autograd.Function):
 
 
 # ============================================================================ affine
+def affine_sites(v, params, mask, log0, layout, inverse):
+    """nf_affine_sites: (value, logJ, per-site log-derivative) of an affine / shift layer; inference only."""
+    _require_device(v, params, mask, log0)
+    if v.dtype not in (torch.float32, torch.float64) or params.dtype != v.dtype:
+        raise TypeError(f"per-site densities are built for float32 / float64 fields; got {v.dtype} / {params.dtype}")
+    B, V = v.shape
+    v, params = v.detach().contiguous(), params.detach().contiguous()
+    out, sites = torch.empty_like(v), torch.empty_like(v)
+    logj = torch.empty(B, dtype=v.dtype, device=v.device)
+    ws = _workspace(min(B, MAX_B), V, v.device)
+    for b0 in range(0, B, MAX_B):
+        b1 = min(B, b0 + MAX_B)
+        l0 = log0[b0:b1] if log0 is not None else None
+        _check(load().nf_affine_sites(_ptr(v[b0:b1]), _ptr(params[b0:b1]), _ptr(mask), _ptr(l0), _ptr(out[b0:b1]),
+                                      _ptr(logj[b0:b1]), _ptr(sites[b0:b1]), b1 - b0, V, params.shape[1], layout,
+                                      int(bool(inverse)), _ptr(ws), ws.numel(), _dtype_code(v), _stream()),
+               "nf_affine_sites")
+    return out, logj, sites
+
+
 class AffineCouplingFn(torch.autograd.Function):
     """Affine (n_ch = 2) or shift (n_ch = 1) coupling on the active sublattice."""
 

@@ -18,6 +18,7 @@ struct AffArgs {
   const void *grad_logj;
   void *grad_in;
   void *grad_params;
+  void *site_out;            // optional (B,V): the log-derivative of every site (-|s| / +|s|), 0 at frozen sites
   int64_t V, Vp, units;
   int n_ch, iters;
 };
@@ -85,6 +86,11 @@ __global__ __launch_bounds__(kBlock) void affine_kernel(AffArgs A) {
     }
     if (PAIR) Store<T, SX>::st2(out, u, off ? T(0) : val, off ? val : T(0));
     else Store<T, SX>::st(out, u, val);
+    if (A.site_out) {         // propagate_density (src/nn/_core.py:19,38-42): nothing summed
+      SX *so = static_cast<SX *>(A.site_out) + int64_t(b) * A.V;
+      if (PAIR) Store<T, SX>::st2(so, u, off ? T(0) : ls, off ? ls : T(0));
+      else Store<T, SX>::st(so, u, ls);
+    }
     acc += double(ls);
   }
   const double tot = block_sum(acc, red);
@@ -167,10 +173,11 @@ static int fill(AffArgs &A, int64_t B, int64_t V, int n_ch, int layout, const ui
 template <typename T, bool INV, typename SX = T, typename SP = T>
 static int run_map(const void *v, const void *params, const uint8_t *mask, const void *log0, void *out,
                    void *logj, int64_t B, int64_t V, int n_ch, int layout, void *ws, size_t ws_bytes,
-                   hipStream_t stream) {
+                   hipStream_t stream, void *site_out = nullptr) {
   AffArgs A{};
   int rc = fill(A, B, V, n_ch, layout, mask);
   if (rc) return rc;
+  A.site_out = site_out;
   NF_REQUIRE(v && params && out && logj, "nf_affine: NULL tensor pointer");
   if (B == 0) return NF_OK;
   const Tiling t = make_tiling(A.units, B);
@@ -249,5 +256,21 @@ extern "C" int nf_affine_vjp(const void *v, const void *params, const uint8_t *m
                    : run_vjp<double, false>(v, params, mask, grad_out, grad_logj, grad_in, grad_params, B, V, n_ch, layout, s);
   }
   set_error("nf_affine_vjp: unsupported dtype %d", dtype);
+  return NF_EINVAL;
+}
+
+// nf_affine_fwd / nf_affine_inv with the log-derivative of every site written beside the sum (fp32 / fp64).
+extern "C" int nf_affine_sites(const void *v, const void *params, const uint8_t *mask, const void *log0, void *out,
+                               void *logj, void *site_out, int64_t B, int64_t V, int n_ch, int layout, int inverse,
+                               void *workspace, size_t workspace_bytes, int dtype, void *stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  NF_REQUIRE(site_out != nullptr, "nf_affine_sites: site_out is NULL");
+  if (dtype == NF_F32)
+    return inverse ? run_map<float, true>(v, params, mask, log0, out, logj, B, V, n_ch, layout, workspace, workspace_bytes, s, site_out)
+                   : run_map<float, false>(v, params, mask, log0, out, logj, B, V, n_ch, layout, workspace, workspace_bytes, s, site_out);
+  if (dtype == NF_F64)
+    return inverse ? run_map<double, true>(v, params, mask, log0, out, logj, B, V, n_ch, layout, workspace, workspace_bytes, s, site_out)
+                   : run_map<double, false>(v, params, mask, log0, out, logj, B, V, n_ch, layout, workspace, workspace_bytes, s, site_out);
+  set_error("nf_affine_sites: unsupported dtype %d", dtype);
   return NF_EINVAL;
 }

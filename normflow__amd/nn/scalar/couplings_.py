@@ -101,7 +101,20 @@ class Coupling_(Module_, ABC):
     def _check_density(self):
         if self.propagate_density:
             raise NotImplementedError("propagate_density=True (per-site densities) is not provided by "
-                                      "the fused kernels, which reduce log|J| per sample")
+                                      "this coupling's kernels, which reduce log|J| per sample")
+
+    def _affine_density_atom(self, inverse, x_active, x_frozen, parity, net, log0):
+        """propagate_density (nn/_core.py:19,38-42) for the affine / shift layers: log0 + the log-derivative of every site
+        (nf_affine_sites), nothing summed.  Inference only."""
+        if torch.is_grad_enabled() and (x_active.requires_grad or x_frozen.requires_grad
+                                        or any(p.requires_grad for p in net.parameters())):
+            raise NotImplementedError("propagate_density=True is an inference path here (per-site densities have no VJP "
+                                      "kernel); wrap the call in torch.no_grad()")
+        B = x_active.shape[0]
+        act = self._activity(parity, x_active.shape[1:], x_active.device)
+        params, layout = self._params(net, x_frozen, None)
+        val, _, sites = _hip.affine_sites(x_active.reshape(B, -1), params, act, None, layout, inverse)
+        return val.reshape(x_active.shape), log0 + sites.reshape(x_active.shape)
 
     def _params(self, net, x_frozen, parity=None):
         """Run the parameter net; return raw logits as (B, C, V) [or (B, C, V/2)] and the
@@ -149,6 +162,8 @@ class ShiftCoupling_(Coupling_):
     """y = purify(x + t) (couplings_.py:107-116); log|J| unchanged."""
 
     def _atom(self, inverse, *, x_active, x_frozen, parity, net, log0=0):
+        if self.propagate_density:
+            return self._affine_density_atom(inverse, x_active, x_frozen, parity, net, log0)
         k = lambda v, p, l0, act, layout: _hip.AffineCouplingFn.apply(v, p, l0, act, layout, inverse)
         val, lj = self._run_atom(k, x_active, x_frozen, parity, net, log0, 1)
         return val, (lj if torch.is_tensor(log0) or log0 != 0 else log0)
@@ -197,6 +212,8 @@ class AffineCoupling_(Coupling_):
         return val.reshape(x_active.shape), lj
 
     def _atom(self, inverse, *, x_active, x_frozen, parity, net, log0=0):
+        if self.propagate_density:
+            return self._affine_density_atom(inverse, x_active, x_frozen, parity, net, log0)
         fused = self._fused_atom(inverse, x_active, x_frozen, parity, net, log0)
         if fused is not None:
             return fused

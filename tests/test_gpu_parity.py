@@ -1661,3 +1661,44 @@ def test_conv_wgrad_split16_kernel_vs_autograd(lattice, cin, cout, B):
             gw32, gb32 = _hip.conv_weight_grad(xd, god, (3,) * 4)
         for got, want in ((gw, gw_ref), (gb, gb_ref), (gw32, gw_ref), (gb32, gb_ref)):
             assert float((got.double().cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("kind", ["affine", "shift"])
+def test_affine_propagate_density(kind, dtype):
+    """propagate_density (nn/_core.py:19,38-42) on the affine / shift couplings: nf_affine_sites returns -|s| (forward) / +|s|
+    (inverse) per active site, 0 elsewhere and for a shift layer; against the oracle's (t, s) of the same net, and summing
+    to the layer's log|J|; the values of the map are those of the summed path, bit for bit."""
+    torch.manual_seed(3)
+    shape, B = (6, 4, 8), 3
+    nch = 2 if kind == "affine" else 1
+    net = ConvAct(1, nch, 3, conv_dim=3, hidden_sizes=[4], acts=['tanh', None]).to(DEV, dtype)
+    mask = EvenOddMask(shape=shape)
+    cls = AffineCoupling_ if kind == "affine" else ShiftCoupling_
+    cpl = cls([net, net], mask=mask).to(DEV)
+    x = torch.randn((B,) + shape, device=DEV, dtype=dtype)
+    convs = [mod for mod in net if hasattr(mod, 'weight')]
+    layers = [(c.weight.double().cpu(), c.bias.double().cpu()) for c in convs]
+    tol = 1e-10 if dtype == torch.float64 else 1e-5
+    with torch.no_grad():
+        y_ref, lj_ref = cpl(x)
+        cpl.propagate_density = True
+        try:
+            y, dens = cpl(x)
+            assert dens.shape == x.shape and torch.equal(y, y_ref)
+            lj_sum = dens.reshape(B, -1).double().sum(1)
+            if torch.is_tensor(lj_ref):
+                assert rel(lj_sum, lj_ref) <= (1e-12 if dtype == torch.float64 else 2e-6)
+            else:
+                assert float(lj_sum.abs().max()) == 0.0
+            # first layer against the oracle: density = -|s| at the active sites of parity 0
+            am = O.channel_mask(shape, 0)
+            xa, xf = x * am.to(DEV, dtype), x * (1 - am).to(DEV, dtype)
+            _, d0 = cpl.atomic_forward(x_active=xa, x_frozen=xf, parity=0, net=net, log0=0)
+            out = O.conv_act(xf.double().cpu().unsqueeze(1), layers, ['tanh', None])
+            want = -out[:, 1].abs() * am if kind == "affine" else torch.zeros_like(out[:, 0])
+            assert rel(d0, want) <= tol
+            xb, back = cpl.backward(y, dens)
+            assert rel(xb, x) <= 100 * tol and float(back.abs().max()) <= 100 * tol
+        finally:
+            cpl.propagate_density = False
