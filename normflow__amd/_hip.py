@@ -72,10 +72,13 @@ PROTOTYPES = {
     "nf_act_vjp": (_I, [_P, _P, _P, _I64, _I, _I, _P]),
     "nf_conv_wgrad_cols": (_I, [_I, _I]),
     "nf_conv_wgrad": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I, _P]),
+    "nf_planes_to_split16": (_I, [_P, _P, _P, _I64, _I, C.POINTER(C.c_int32), _P]),
+    "nf_conv_dgrad_split16": (_I, [_P, _P, _P, _P, _I64, C.POINTER(C.c_int32), _P, _I, _I, _P]),
+    "nf_absmax_bits": (_I, [_P, _I64, _P, _P]),
     "nf_expand_pairs": (_I, [_P, _P, _I64, C.POINTER(C.c_int32), _I, _I, _P]),
     "nf_conv_wgrad_split16_supported": (_I, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I]),
     "nf_conv_wgrad_split16_workspace": (_SZ, [_I64, C.POINTER(C.c_int32), _I]),
-    "nf_conv_wgrad_split16": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _P, _SZ, _P]),
+    "nf_conv_wgrad_split16": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _P, _P, _SZ, _P]),
     "nf_conv_rqs_supported": (_I, [_I, _I]),
     "nf_conv_last_path": (_I, []),
     "nf_conv_split16_supported": (_I, [_P, _P, _I, _I, _I]),
@@ -776,9 +779,17 @@ def _lat4(lat, ksize):
     return (C.c_int32 * 4)(*([1] * (4 - d) + list(lat))), (C.c_int32 * 4)(*([1] * (4 - d) + list(ksize)))
 
 
-def conv_weight_grad(x, gz, ksize):
+def absmax_bits(t):
+    """nf_absmax_bits: max |t| of an fp32 tensor as float bits in a 1-element int32 device tensor (no host sync)."""
+    bits = torch.empty(1, dtype=torch.int32, device=t.device)
+    _check(load().nf_absmax_bits(_ptr(t), t.numel(), _ptr(bits), _stream()), "nf_absmax_bits")
+    return bits
+
+
+def conv_weight_grad(x, gz, ksize, bits=None):
     """(grad_weight (cout, cin, *k), grad_bias (cout)) of a circular conv layer from its input x
-    (B, cin, *L) and the full-lattice pre-activation cotangent gz (B, cout, *L): nf_conv_wgrad."""
+    (B, cin, *L) and the full-lattice pre-activation cotangent gz (B, cout, *L): nf_conv_wgrad, or nf_conv_wgrad_split16
+    (`bits`: absmax_bits(gz) if the caller has it already)."""
     lib = load()
     B, cin = x.shape[:2]
     cout = gz.shape[1]
@@ -800,8 +811,10 @@ def conv_weight_grad(x, gz, ksize):
             if split:       # fp16 matrix cores, three products per fp32 product (nf_conv_w.hip)
                 need = lib.nf_conv_wgrad_split16_workspace(b1 - b0, lat4, cin)
                 ws = torch.empty(int(need), dtype=torch.uint8, device=x.device)
+                if bits is None:
+                    bits = absmax_bits(gz)      # (of the whole cotangent: any power of two that fits the maximum will do)
                 _check(lib.nf_conv_wgrad_split16(_ptr(x[b0:b1]), _ptr(part[b0:b1]), _ptr(buf), b1 - b0, lat4, k4, cin,
-                                                 c1 - c0, _ptr(ws), ws.numel(), _stream()), "nf_conv_wgrad_split16")
+                                                 c1 - c0, _ptr(bits), _ptr(ws), ws.numel(), _stream()), "nf_conv_wgrad_split16")
             else:
                 _check(lib.nf_conv_wgrad(_ptr(x[b0:b1]), _ptr(part[b0:b1]), _ptr(buf), b1 - b0, lat4, k4, cin,
                                          c1 - c0, _dtype_code(x), _stream()), "nf_conv_wgrad")
@@ -813,6 +826,61 @@ def conv_weight_grad(x, gz, ksize):
     return gw, gb
 
 
+def conv_input_grad_split16(gz, wt, bits=None):
+    """Gradient w.r.t. the input of a 3^4 layer with 8 input channels on the split-fp16 chain: gz (B, C, *L) fp32 cotangent of
+    the layer's pre-activation, wt (8, C, 3, 3, 3, 3) its weights flipped and transposed.  The C channels go through the
+    hidden-layer kernel in groups of 8 (nf_planes_to_split16 + nf_conv_dgrad_split16).  None when the shape does not qualify
+    (the caller then runs the fp32 kernel)."""
+    lib = load()
+    if (gz.dtype != torch.float32 or gz.dim() != 6 or wt.shape[0] != 8 or tuple(wt.shape[2:]) != (3, 3, 3, 3)
+            or not lib.nf_get_option(OPT_SPLIT16)):
+        return None
+    B, Cc = gz.shape[:2]
+    lattice = tuple(gz.shape[2:])
+    lat4, k4 = _lat4(lattice, (3, 3, 3, 3))
+    if not lib.nf_conv_split16_supported(lat4, k4, 8, 8, ACT_CODES['tanh']) or B > 65535:
+        return None
+    G = (Cc + 7) // 8
+    V = gz[0, 0].numel()
+    gz = gz.contiguous()
+    g16 = torch.empty((G, B, V, 16), dtype=torch.float16, device=gz.device)
+    if bits is None:
+        bits = absmax_bits(gz)
+    _check(lib.nf_planes_to_split16(_ptr(gz), _ptr(g16), _ptr(bits), B, Cc, lat4, _stream()), "nf_planes_to_split16")
+    gx = torch.empty((B, 8) + lattice, dtype=torch.float32, device=gz.device)
+    wpad = wt.new_zeros((8, 8 * G, 3, 3, 3, 3), dtype=torch.float32)
+    wpad[:, :Cc] = wt.float()
+    for g in range(G):
+        wsp = pack_conv_weight_split16_two_site(wpad[:, 8 * g:8 * g + 8].contiguous())
+        _check(lib.nf_conv_dgrad_split16(_ptr(g16[g]), _ptr(wsp), None, _ptr(gx), B, lat4, _ptr(bits), int(g > 0), 0,
+                                         _stream()), "nf_conv_dgrad_split16")
+    return gx
+
+
+def conv_hidden_planes_split16(x, weight, bias, act):
+    """A forward 8 -> 8 layer (3^4, tanh or no activation) on the split-fp16 chain with fp32 planes in and out -- the form
+    autograd keeps (ConvFn): nf_absmax_bits + nf_planes_to_split16 + nf_conv_dgrad_split16.  None when the shape does not qualify."""
+    lib = load()
+    if (x.dtype != torch.float32 or x.dim() != 6 or tuple(weight.shape) != (8, 8, 3, 3, 3, 3) or act not in (0, ACT_CODES['tanh'])
+            or not lib.nf_get_option(OPT_SPLIT16)):
+        return None
+    B = x.shape[0]
+    lattice = tuple(x.shape[2:])
+    lat4, k4 = _lat4(lattice, (3, 3, 3, 3))
+    if not lib.nf_conv_split16_supported(lat4, k4, 8, 8, ACT_CODES['tanh']) or B > 65535 or not _weights_fit_fp16(weight):
+        return None
+    V = x[0, 0].numel()
+    x16 = torch.empty((1, B, V, 16), dtype=torch.float16, device=x.device)
+    bits = absmax_bits(x)                        # (any input range: the pair tensor is scaled like a cotangent's)
+    _check(lib.nf_planes_to_split16(_ptr(x), _ptr(x16), _ptr(bits), B, 8, lat4, _stream()), "nf_planes_to_split16")
+    wsp = pack_conv_weight_split16_two_site(weight.detach().float())
+    out = torch.empty_like(x)
+    b = None if bias is None else bias.detach().float().contiguous()
+    _check(lib.nf_conv_dgrad_split16(_ptr(x16[0]), _ptr(wsp), _ptr(b), _ptr(out), B, lat4, _ptr(bits), 0, int(act), _stream()),
+           "nf_conv_dgrad_split16")
+    return out
+
+
 class ConvFn(torch.autograd.Function):
     """One circular conv layer + activation, forward and backward on the MFMA kernels:
     forward nf_conv_fwd; backward nf_act_vjp, nf_conv_fwd with flipped / transposed weights
@@ -822,7 +890,11 @@ class ConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, act, compact, parity):
         _require_device(x, weight, bias)
         x = x.contiguous()
-        out = _conv_launch(x, weight.detach(), bias, act, compact, parity)
+        out = None
+        if not compact and x.dim() == 6 and x.shape[1] == 8 and weight.shape[0] == 8:
+            out = conv_hidden_planes_split16(x, weight, bias, act)      # 8 -> 8 layer of a lattice network: the split-fp16 kernel
+        if out is None:
+            out = _conv_launch(x, weight.detach(), bias, act, compact, parity)
         ctx.save_for_backward(x, weight, out if act else None)
         ctx.act, ctx.compact, ctx.parity, ctx.has_bias = act, compact, parity, bias is not None
         return out
@@ -841,12 +913,15 @@ class ConvFn(torch.autograd.Function):
             gz = _compact_to_full(gz, x.shape[2:], ctx.parity)
         gz = gz.reshape((x.shape[0], weight.shape[0]) + tuple(x.shape[2:])).contiguous()
         gx = gw = gb = None
+        bits = absmax_bits(gz) if (gz.dtype == torch.float32 and gz.dim() == 6 and lib.nf_get_option(OPT_SPLIT16)) else None
         if ctx.needs_input_grad[0]:
             kdims = list(range(2, weight.dim()))
             wt = weight.detach().flip(kdims).transpose(0, 1).contiguous()
-            gx = _conv_launch(gz, wt, None, 0, False, 0)
+            gx = conv_input_grad_split16(gz, wt, bits)
+            if gx is None:
+                gx = _conv_launch(gz, wt, None, 0, False, 0)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw, gb = conv_weight_grad(x, gz, weight.shape[2:])
+            gw, gb = conv_weight_grad(x, gz, weight.shape[2:], bits)
             if not ctx.has_bias:
                 gb = None
         return gx, gw, gb, None, None, None

@@ -70,7 +70,20 @@ struct ConvArgs {
   int nboxes;
   int out_split16;          // two-site layers with 8 output channels: store (hi, lo) fp16 pairs, channel-last, 32 bytes per site
   int wide_no, wide_llpr;   // nf_conv_pipe.hip wide staging: row blocks per wave (0 = narrow), log2(lanes per row)
+  const unsigned *gscale_bits;   // nf_conv_dgrad_split16: bits of max |cotangent| the input pair tensor was scaled by (or null)
+  int accumulate;                // ... add to the output planes instead of overwriting them
 };
+
+// The power of two that brings a tensor whose largest magnitude has the bits *absmax to [2^12, 2^13): cotangents of a mean
+// over a batch are far below fp16's normal range (nf_conv_w.hip, nf_conv_dgrad_split16).
+__device__ __forceinline__ float pow2_scale_for(const unsigned *absmax) {
+  if (!absmax) return 1.f;
+  const float mx = __uint_as_float(*absmax);
+  if (!(mx > 0.f) || !(mx < 3.0e38f)) return 1.f;
+  int e;
+  (void)frexpf(mx, &e);                       // mx = f 2^e, f in [0.5, 1)
+  return ldexpf(1.f, 13 - e);
+}
 
 // The fp16 (hi, lo) pair tensor exchanged by the split-fp16 kernels (include/normflow_hip.h, NF_OUT_SPLIT16) is row-major:
 // a lattice row (L3 sites of the fastest axis) is L3*32 bytes = [hi | lo][even sites | odd sites][L3/2 slots][8 channels]

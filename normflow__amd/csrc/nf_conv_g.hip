@@ -130,6 +130,7 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
     kc0[r] = 2.885390081777927f * bv4[r];      // 2 log2(e) x bias
   }
   const float kc1 = 2.885390081777927f * kInvWScale;
+  [[maybe_unused]] const float descale = kInvWScale / pow2_scale_for(A.gscale_bits);      // EPI = 3
 
   // ---- A-fragment addressing.  Lane (pair p, k-group g) reads tap g of its pair q = 16 hs + p: site 2q + g - 1 -- parity block
   // (g + 1) & 1, slot q + (g >> 1) of the pair tensor's row (pair_row_offset), i.e. LOCAL slot j = p + (g >> 1) of the segment's
@@ -216,7 +217,11 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
     decode(ci, b, i0, i1, hs);
     const int qq = 16 * hs + p;
     lane_ok = qq < HP;
-    if (EPI > 0) {
+    if (EPI == 3) {
+      // fp32 channel planes (B, 8, V): element of channel 0 at this lane's site, row (x0, x1, plane te)
+      const int x0 = 2 * i0 + (q >> 1), x1 = 2 * i1 + (q & 1);
+      fcol = int64_t(b) * 8 * A.V + ((int64_t(x0) * A.L[1] + x1) * L2 + te) * int64_t(L3) + (lane_ok ? 2 * qq + (g >> 1) : 0);
+    } else if (EPI > 0) {
       const int x0 = 2 * i0 + (q >> 1), x1 = 2 * i1 + (q & 1);
       // the active site of a pair of row (x0, x1, x2): site parity (A.parity + x0 + x1 + x2) & 1; planes 2s + te: x2 parity = te
       const int a = (A.parity + x0 + x1 + te) & 1;
@@ -275,6 +280,17 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
         unsigned char *d = pout + plane_o;
         *reinterpret_cast<f16x4 *>(d) = hi;
         *reinterpret_cast<f16x4 *>(d + HB) = lo;
+      }
+    } else if constexpr (EPI == 3) {
+      // -> descaled, as they are (an input gradient has no activation), to fp32 channel planes; optionally added to them
+      if (plane_ok) {
+        float *d = static_cast<float *>(A.out) + pfield + int64_t(4 * (g & 1)) * A.V;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = (prev[r] + pa[r]) * descale + bv4[r];
+          if (A.act == kActTanh) v = tanh_affine(v, 2.885390081777927f, 0.f);
+          d[int64_t(r) * A.V] = A.accumulate ? d[int64_t(r) * A.V] + v : v;
+        }
       }
     } else {
       // -> (t, s) of the active site -> the affine map on the field, log-det -= / += |s|
@@ -418,7 +434,9 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
     pout = ocol + unsigned(2 * s) * unsigned(RB);
     plane_o = lane_o;
     plane_ok = lane_ok;
-    if (EPI > 0) {
+    if (EPI == 3) {
+      pfield = fcol + int64_t(2 * s) * L3;
+    } else if (EPI > 0) {
       pfield = fcol + int64_t(2 * s) * HP;
       pslot = col_slot;
     }
@@ -456,7 +474,7 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
 #endif
   // ---- the last step's epilogue
   if (have_prev) epilogue((nsteps_total - 1) & 1);
-  if (EPI > 0) flush();
+  if (EPI == 1 || EPI == 2) flush();
   wait_vm<0>();                               // no DMA may outlive the workgroup's LDS allocation
 }
 
@@ -500,10 +518,10 @@ static int launch_g2(ConvArgs &A, const int32_t *lattice, int64_t B, int epi, hi
   int rc;
   if (segm) {
     constexpr int lds = g2::Geo<true>::LDS_BYTES;
-    rc = epi == 0 ? go(&conv_g2_kernel<true, 0>, lds) : (epi == 1 ? go(&conv_g2_kernel<true, 1>, lds) : go(&conv_g2_kernel<true, 2>, lds));
+    rc = epi == 0 ? go(&conv_g2_kernel<true, 0>, lds) : (epi == 1 ? go(&conv_g2_kernel<true, 1>, lds) : (epi == 2 ? go(&conv_g2_kernel<true, 2>, lds) : go(&conv_g2_kernel<true, 3>, lds)));
   } else {
     constexpr int lds = g2::Geo<false>::LDS_BYTES;
-    rc = epi == 0 ? go(&conv_g2_kernel<false, 0>, lds) : (epi == 1 ? go(&conv_g2_kernel<false, 1>, lds) : go(&conv_g2_kernel<false, 2>, lds));
+    rc = epi == 0 ? go(&conv_g2_kernel<false, 0>, lds) : (epi == 1 ? go(&conv_g2_kernel<false, 1>, lds) : (epi == 2 ? go(&conv_g2_kernel<false, 2>, lds) : go(&conv_g2_kernel<false, 3>, lds)));
   }
   if (rc) return rc;
   return check_launch(what);
@@ -555,4 +573,28 @@ extern "C" int nf_conv_affine_split16(const void *in16, const void *wsplit, cons
   const int rc = launch_g2(A, lattice, B, inverse ? 2 : 1, stream, "nf_conv_affine_split16");
   if (rc) return rc;
   return launch_finalize<float>(A.partial, blocks, log0, logj, B, stream);
+}
+
+// The hidden-layer kernel with fp32 channel planes (B, 8, V) out -- for training, whose other kernels read planes:
+//  * the input gradient of an 8 -> 8 layer, or one 8-channel group of the input gradient of a wider layer: the layer's weights
+//    flipped and transposed (packed like a forward layer's), bias NULL, act 0; in16 is the cotangent's pair tensor, scaled by
+//    the power of two that belongs to *absmax_bits (nf_planes_to_split16); the planes are written, or added to when
+//    `accumulate` (the groups of a 46 -> 8 gradient take turns);
+//  * a forward 8 -> 8 layer whose output autograd keeps: bias, act = tanh (or 0), absmax_bits NULL.
+extern "C" int nf_conv_dgrad_split16(const void *in16, const void *wsplit, const void *bias, void *gx, int64_t B,
+                                     const int32_t *lattice, const void *absmax_bits, int accumulate, int act,
+                                     void *stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  NF_REQUIRE(in16 && wsplit && gx && lattice, "nf_conv_dgrad_split16: NULL pointer");
+  const int32_t k3[4] = {3, 3, 3, 3};
+  NF_REQUIRE(nf_conv_split16_supported(lattice, k3, 8, 8, kActTanh), "nf_conv_dgrad_split16: lattice not supported (needs a fastest axis of 32 + 16 n sites, even other extents)");
+  NF_REQUIRE(B >= 0 && B <= 65535, "nf_conv_dgrad_split16: batch outside [0, 65535]");
+  if (B == 0) return NF_OK;
+  ConvArgs A{};
+  NF_REQUIRE(act == kActNone || act == kActTanh, "nf_conv_dgrad_split16: activation %d (none or tanh)", act);
+  A.in = in16; A.wfrag = wsplit; A.bias = bias; A.out = gx;
+  A.act = act;
+  A.gscale_bits = static_cast<const unsigned *>(absmax_bits);
+  A.accumulate = accumulate ? 1 : 0;
+  return launch_g2(A, lattice, B, 3, stream, "nf_conv_dgrad_split16");
 }

@@ -52,13 +52,7 @@ struct Args {
 
 extern __shared__ __align__(16) unsigned char smem_w[];
 
-__device__ __forceinline__ float gz_scale(const unsigned *absmax) {
-  const float mx = __uint_as_float(*absmax);
-  if (!(mx > 0.f) || !(mx < 3.0e38f)) return 1.f;
-  int e;
-  (void)frexpf(mx, &e);                       // mx = f 2^e, f in [0.5, 1)
-  return ldexpf(1.f, 13 - e);                 // scaled maximum in [2^12, 2^13)
-}
+__device__ __forceinline__ float gz_scale(const unsigned *absmax) { return pow2_scale_for(absmax); }
 
 __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ p, int64_t n, unsigned *out) {
   float m = 0.f;
@@ -351,6 +345,34 @@ __global__ __launch_bounds__(256) void expand_pairs_kernel(const T *__restrict__
   (void)L0;
 }
 
+// fp32 channel planes (B, C, V) -> G = ceil(C / 8) pair tensors (G, B, V, 16 halfs) of 8 channels each (zeros past C), every
+// value multiplied by the power of two of *absmax: the cotangent as the split-fp16 conv kernels read it (nf_conv_dgrad_split16).
+__global__ __launch_bounds__(256) void planes_to_pairs_kernel(const float *__restrict__ src, unsigned char *__restrict__ dst, int64_t B,
+                                                              int C, int64_t V, int L3, const unsigned *absmax) {
+  const float scale = pow2_scale_for(absmax);
+  const int G = (C + 7) >> 3;
+  const int64_t total = int64_t(G) * B * V;
+  for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < total; i += int64_t(gridDim.x) * 256) {
+    const int64_t site = i % V;
+    const int64_t gb = i / V;                  // g * B + b
+    const int b = int(gb % B), g = int(gb / B);
+    f16x8 hi, lo;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int ch = 8 * g + c;
+      const float v = ch < C ? src[(int64_t(b) * C + ch) * V + site] * scale : 0.f;
+      const _Float16 h = static_cast<_Float16>(v);
+      hi[c] = h;
+      lo[c] = static_cast<_Float16>(v - static_cast<float>(h));
+    }
+    const int64_t row = site / L3;
+    const int x3 = int(site - row * L3);
+    unsigned char *d = dst + (gb * V + row * L3) * 32 + pair_row_offset(x3, L3);
+    *reinterpret_cast<f16x8 *>(d) = hi;
+    *reinterpret_cast<f16x8 *>(d + L3 * 16) = lo;
+  }
+}
+
 // gw[o][c] += (sum over the workgroups' partials, in order) / scale
 __global__ __launch_bounds__(256) void wgrad16_reduce_kernel(const float *__restrict__ partial, float *__restrict__ gw, int nparts, int ncols,
                                                              int nused, int rows, const unsigned *absmax) {
@@ -387,8 +409,8 @@ extern "C" size_t nf_conv_wgrad_split16_workspace(int64_t B, const int32_t *latt
 }
 
 extern "C" int nf_conv_wgrad_split16(const void *in, const void *gz, void *gw, int64_t B, const int32_t *lattice,
-                                     const int32_t *ksize, int cin, int cout, void *workspace, size_t workspace_bytes,
-                                     void *stream) {
+                                     const int32_t *ksize, int cin, int cout, const void *absmax_bits, void *workspace,
+                                     size_t workspace_bytes, void *stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   NF_REQUIRE(in && gz && gw && lattice && ksize, "nf_conv_wgrad_split16: NULL pointer");
   NF_REQUIRE(nf_conv_wgrad_split16_supported(lattice, ksize, cin, cout),
@@ -410,14 +432,12 @@ extern "C" int nf_conv_wgrad_split16(const void *in, const void *gz, void *gw, i
     set_error("nf_conv_wgrad_split16: workspace %zu B < %zu B needed", workspace_bytes, need);
     return NF_EWORKSPACE;
   }
-  unsigned *absmax = static_cast<unsigned *>(workspace);
+  NF_REQUIRE(absmax_bits != nullptr, "nf_conv_wgrad_split16: absmax_bits is NULL (nf_absmax_bits of gz)");
+  const unsigned *absmax = static_cast<const unsigned *>(absmax_bits);
   A.absmax = absmax;
   A.partial = reinterpret_cast<float *>(static_cast<unsigned char *>(workspace) + 256);
   NF_REQUIRE(hipMemsetAsync(workspace, 0, need, s) == hipSuccess, "nf_conv_wgrad_split16: hipMemsetAsync failed");
-  const int64_t ngz = B * cout * A.V;
-  hipLaunchKernelGGL(wg::absmax_kernel, dim3(2048), dim3(256), 0, s, A.gz, ngz, absmax);
-  int rc = check_launch("wgrad absmax kernel");
-  if (rc) return rc;
+  int rc;
   const int MT = (cout + 15) >> 4;
   const size_t lds = size_t(wg::NSLOT) * 9 * cin * wg::RS + 2 * 48 * wg::GS;
 #define NF_W16(MTV, CINV)                                                                                              \
@@ -462,4 +482,33 @@ extern "C" int nf_expand_pairs(const void *compact, void *full, int64_t rows, co
     return NF_EINVAL;
   }
   return check_launch("expand pairs kernel");
+}
+
+// max |x| of an fp32 tensor as the bits of a float in device memory (4 bytes): the measure the split-fp16 training kernels
+// scale a cotangent by (one pass, shared by the weight gradient and the input gradient of a layer).
+extern "C" int nf_absmax_bits(const void *x, int64_t n, void *bits, void *stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  NF_REQUIRE(x && bits && n >= 0, "nf_absmax_bits: bad arguments");
+  NF_REQUIRE(hipMemsetAsync(bits, 0, 4, s) == hipSuccess, "nf_absmax_bits: hipMemsetAsync failed");
+  if (n == 0) return NF_OK;
+  hipLaunchKernelGGL(wg::absmax_kernel, dim3(2048), dim3(256), 0, s, static_cast<const float *>(x), n, static_cast<unsigned *>(bits));
+  return check_launch("absmax kernel");
+}
+
+// fp32 channel planes (B, C, V) as the split-fp16 kernels read them: ceil(C / 8) pair tensors (G, B, V, 16 halfs), multiplied
+// by the power of two that brings the maximum in *absmax_bits to [2^12, 2^13) (absmax_bits NULL: as they are -- activations).
+extern "C" int nf_planes_to_split16(const void *gz, void *out16, const void *absmax_bits, int64_t B, int C,
+                                    const int32_t *lattice, void *stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  NF_REQUIRE(gz && out16 && lattice, "nf_planes_to_split16: NULL pointer");
+  NF_REQUIRE(B >= 0 && C >= 1, "nf_planes_to_split16: bad sizes");
+  NF_REQUIRE(lattice[3] >= 2 && (lattice[3] & 1) == 0, "nf_planes_to_split16: the fastest axis must be even");
+  const int64_t V = int64_t(lattice[0]) * lattice[1] * lattice[2] * lattice[3];
+  if (B == 0 || V == 0) return NF_OK;
+  const int64_t total = int64_t((C + 7) / 8) * B * V;
+  const int64_t want = (total + 255) / 256;
+  hipLaunchKernelGGL(wg::planes_to_pairs_kernel, dim3(unsigned(want < 16384 ? want : 16384)), dim3(256), 0, s,
+                     static_cast<const float *>(gz), static_cast<unsigned char *>(out16), B, C, V, lattice[3],
+                     static_cast<const unsigned *>(absmax_bits));
+  return check_launch("planes to pairs kernel");
 }
