@@ -827,12 +827,13 @@ def conv_weight_grad(x, gz, ksize, bits=None):
 
 
 def conv_input_grad_split16(gz, wt, bits=None):
-    """Gradient w.r.t. the input of a 3^4 layer with 8 input channels on the split-fp16 chain: gz (B, C, *L) fp32 cotangent of
-    the layer's pre-activation, wt (8, C, 3, 3, 3, 3) its weights flipped and transposed.  The C channels go through the
+    """Gradient w.r.t. the input of a 3^4 layer with up to 8 input channels on the split-fp16 chain: gz (B, C, *L) fp32 cotangent
+    of the layer's pre-activation, wt (cin, C, 3, 3, 3, 3) its weights flipped and transposed.  The C channels go through the
     hidden-layer kernel in groups of 8 (nf_planes_to_split16 + nf_conv_dgrad_split16).  None when the shape does not qualify
     (the caller then runs the fp32 kernel)."""
     lib = load()
-    if (gz.dtype != torch.float32 or gz.dim() != 6 or wt.shape[0] != 8 or tuple(wt.shape[2:]) != (3, 3, 3, 3)
+    cin = wt.shape[0]                  # channels of the layer's input = of the gradient (fewer than 8: zero weight rows)
+    if (gz.dtype != torch.float32 or gz.dim() != 6 or cin > 8 or tuple(wt.shape[2:]) != (3, 3, 3, 3)
             or not lib.nf_get_option(OPT_SPLIT16)):
         return None
     B, Cc = gz.shape[:2]
@@ -849,12 +850,12 @@ def conv_input_grad_split16(gz, wt, bits=None):
     _check(lib.nf_planes_to_split16(_ptr(gz), _ptr(g16), _ptr(bits), B, Cc, lat4, _stream()), "nf_planes_to_split16")
     gx = torch.empty((B, 8) + lattice, dtype=torch.float32, device=gz.device)
     wpad = wt.new_zeros((8, 8 * G, 3, 3, 3, 3), dtype=torch.float32)
-    wpad[:, :Cc] = wt.float()
+    wpad[:cin, :Cc] = wt.float()
     for g in range(G):
         wsp = pack_conv_weight_split16_two_site(wpad[:, 8 * g:8 * g + 8].contiguous())
         _check(lib.nf_conv_dgrad_split16(_ptr(g16[g]), _ptr(wsp), None, _ptr(gx), B, lat4, _ptr(bits), int(g > 0), 0,
                                          _stream()), "nf_conv_dgrad_split16")
-    return gx
+    return gx if cin == 8 else gx[:, :cin].contiguous()
 
 
 def conv_hidden_planes_split16(x, weight, bias, act):

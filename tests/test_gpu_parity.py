@@ -1704,15 +1704,16 @@ def test_affine_propagate_density(kind, dtype):
             cpl.propagate_density = False
 
 
-@pytest.mark.parametrize("lattice,cout,B", [((2, 2, 4, 32), 46, 3), ((4, 2, 2, 32), 8, 2), ((2, 4, 2, 48), 22, 2), ((2, 2, 2, 64), 46, 1)])
-def test_conv_input_grad_split16_vs_autograd(lattice, cout, B):
+@pytest.mark.parametrize("lattice,cout,B,cin", [((2, 2, 4, 32), 46, 3, 8), ((4, 2, 2, 32), 8, 2, 8), ((2, 4, 2, 48), 22, 2, 8),
+                                                    ((2, 2, 2, 64), 46, 1, 8), ((2, 2, 4, 32), 8, 3, 1)])
+def test_conv_input_grad_split16_vs_autograd(lattice, cout, B, cin):
     """nf_planes_to_split16 + nf_conv_dgrad_split16: the gradient w.r.t. the input of an 8 -> cout layer on the split-fp16
     chain (cotangent scaled into fp16's range, 8-channel groups through the hidden-layer kernel, fp32 planes accumulated)
     against autograd through the fp64 oracle convolution, with O(1) and 1e-6 cotangents; the whole ConvFn.backward with it
     (weight and bias gradients from nf_conv_wgrad_split16 where the lattice qualifies).  2e-5 of the largest entry."""
     g = torch.Generator(device='cpu').manual_seed(cout)
-    x = torch.tanh(torch.randn((B, 8) + lattice, generator=g, dtype=torch.float64, device='cpu'))
-    w = 0.3 * torch.randn((cout, 8) + (3,) * 4, generator=g, dtype=torch.float64, device='cpu')
+    x = torch.tanh(torch.randn((B, cin) + lattice, generator=g, dtype=torch.float64, device='cpu'))
+    w = 0.3 * torch.randn((cout, cin) + (3,) * 4, generator=g, dtype=torch.float64, device='cpu')
     bias = torch.randn(cout, generator=g, dtype=torch.float64, device='cpu')
     for gscale in (1.0, 1e-6):
         go = gscale * torch.randn((B, cout) + lattice, generator=g, dtype=torch.float64, device='cpu')
@@ -1728,7 +1729,7 @@ def test_conv_input_grad_split16_vs_autograd(lattice, cout, B):
         wt = wd.detach().flip([2, 3, 4, 5]).transpose(0, 1).contiguous()
         direct = _hip.conv_input_grad_split16(go.to(DEV, torch.float32), wt)
         assert direct is not None and torch.equal(direct, got[0])           # this path ran, and it is deterministic
-    if cout == 8:
+    if cout == 8 and cin == 8:
         # the forward 8 -> 8 layer training keeps as planes (ConvFn.forward): tanh and no activation, inputs beyond [-1, 1] too
         for act, scale in (('tanh', 1.0), (None, 40.0)):
             xs = (scale * x).to(DEV, torch.float32)
