@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NF_VERSION 204 /* 0.2.0 */
+#define NF_VERSION 205 /* 0.2.0 */
 
 /* NF_F16 (nf_rqs_fwd / nf_rqs_inv with knots_len 4/8/16, nf_affine_fwd / nf_affine_inv): x, params and y are IEEE half, the arithmetic is fp32 and
  * log0 / logj are fp32 ("fp16 params / fp32 log-det accumulate", BASELINE config 5). */
@@ -401,6 +401,16 @@ int nf_planes_to_split16(const void *gz, void *out16, const void *absmax_bits, i
                          const int32_t *lattice, void *stream);
 int nf_conv_dgrad_split16(const void *in16, const void *wsplit, const void *bias, void *gx, int64_t B,
                           const int32_t *lattice, const void *absmax_bits, int accumulate, int act, void *stream);
+
+/* The last conv layer 8 -> 46 of a spline coupling's net at the active sites on the split-fp16 kernel (the matrix-core part of
+ * nf_conv_rqs), with the logits written out pair-compact (B, 46, V/2) fp32 instead of consumed: the forward pass of a
+ * training step, which differentiates the spline separately.  in: fp32 channel planes (B, 8, V) (fastest axis of 32 sites)
+ * or, with in_split16, the (B, V, 16) pair tensor; absmax_bits (nf_absmax_bits of the input, or NULL for inputs already in
+ * fp16's range): the input gets / is scaled by the matching power of two and the logits are descaled; wsplit in
+ * NF_WLAYOUT_SPLIT16; bias (46) fp32 or NULL. */
+int nf_conv_last_logits_split16(const void *in, int in_split16, const void *wsplit, const void *bias, void *logits,
+                                int64_t B, const int32_t *lattice, int active_parity, const void *absmax_bits,
+                                void *stream);
 
 /* nf_expand_pairs: a pair-compact tensor (rows, V/2) -- the layout the active-site-only conv output and its cotangent use --
  * to the full lattice (rows, V), zeros at the sites of the other parity; rows = B * channels; lattice[3] even. */

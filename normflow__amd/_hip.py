@@ -75,6 +75,7 @@ PROTOTYPES = {
     "nf_planes_to_split16": (_I, [_P, _P, _P, _I64, _I, C.POINTER(C.c_int32), _P]),
     "nf_conv_dgrad_split16": (_I, [_P, _P, _P, _P, _I64, C.POINTER(C.c_int32), _P, _I, _I, _P]),
     "nf_absmax_bits": (_I, [_P, _I64, _P, _P]),
+    "nf_conv_last_logits_split16": (_I, [_P, _I, _P, _P, _P, _I64, C.POINTER(C.c_int32), _I, _P, _P]),
     "nf_expand_pairs": (_I, [_P, _P, _I64, C.POINTER(C.c_int32), _I, _I, _P]),
     "nf_conv_wgrad_split16_supported": (_I, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I]),
     "nf_conv_wgrad_split16_workspace": (_SZ, [_I64, C.POINTER(C.c_int32), _I]),
@@ -882,6 +883,28 @@ def conv_hidden_planes_split16(x, weight, bias, act):
     return out
 
 
+def conv_last_logits_split16(x, weight, bias, parity):
+    """The forward 8 -> 46 layer at the active sites of parity `parity` on the split-fp16 kernel, logits pair-compact
+    (B, 46, V/2) -- the form autograd keeps (ConvFn with compact=True): nf_absmax_bits + nf_conv_last_logits_split16.  None
+    when the shape does not qualify (fp32 planes in: a fastest axis of 32 sites)."""
+    lib = load()
+    if (x.dtype != torch.float32 or x.dim() != 6 or tuple(weight.shape) != (46, 8, 3, 3, 3, 3) or x.shape[1] != 8
+            or x.shape[-1] != 32 or any(n < 2 or n % 2 for n in x.shape[2:5]) or not lib.nf_get_option(OPT_SPLIT16)
+            or not _weights_fit_fp16(weight)):
+        return None
+    B = x.shape[0]
+    lattice = tuple(x.shape[2:])
+    lat4 = (C.c_int32 * 4)(*lattice)
+    V = x[0, 0].numel()
+    bits = absmax_bits(x)
+    wsp = pack_conv_weight_split16(weight.detach().float())
+    b = None if bias is None else bias.detach().float().contiguous()
+    out = torch.empty((B, 46, V // 2), dtype=torch.float32, device=x.device)
+    _check(lib.nf_conv_last_logits_split16(_ptr(x), 0, _ptr(wsp), _ptr(b), _ptr(out), B, lat4, int(parity), _ptr(bits),
+                                           _stream()), "nf_conv_last_logits_split16")
+    return out
+
+
 class ConvFn(torch.autograd.Function):
     """One circular conv layer + activation, forward and backward on the MFMA kernels:
     forward nf_conv_fwd; backward nf_act_vjp, nf_conv_fwd with flipped / transposed weights
@@ -894,6 +917,8 @@ class ConvFn(torch.autograd.Function):
         out = None
         if not compact and x.dim() == 6 and x.shape[1] == 8 and weight.shape[0] == 8:
             out = conv_hidden_planes_split16(x, weight, bias, act)      # 8 -> 8 layer of a lattice network: the split-fp16 kernel
+        elif compact and act == 0 and x.dim() == 6 and weight.shape[0] == 46:
+            out = conv_last_logits_split16(x, weight, bias, parity)     # ... and its 8 -> 46 layer at the active sites
         if out is None:
             out = _conv_launch(x, weight.detach(), bias, act, compact, parity)
         ctx.save_for_backward(x, weight, out if act else None)

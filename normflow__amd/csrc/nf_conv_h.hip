@@ -229,6 +229,9 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     b += sb_ + carry;
   };
 
+  // the input may come scaled by a power of two (training: activations of unknown range, nf_conv_last_logits_split16)
+  const float in_scale = pow2_scale_for(A.gscale_bits), out_scale = kInvWScale / in_scale;
+
   if (wave < 3) {
     // ============================================================ compute waves: K third `wave` = fastest-axis tap j3
     // Wave w multiplies the 7 slices of tap j3 = w (kernel rows 4i..4i+3, i = 0..6) into ALL three column tiles of all 8
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     f32x4 acc0;               // what slot 0 starts from
     {
       const int co = (W << 4) + (lane & 15);
-      const float b0 = (A.bias && co < C) ? static_cast<const float *>(A.bias)[co] * kWScale : 0.f;
+      const float b0 = (A.bias && co < C) ? static_cast<const float *>(A.bias)[co] * kWScale * in_scale : 0.f;
       acc0 = f32x4{b0, b0, b0, b0};
     }
     f32x4 acc[8][3];
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
           const f32x4 s2 = *(const lds_q *)(pa + PT / 4 + (mt << 4));
           f32x4 v;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = ((acc[mt][0][r] + s1[r]) + s2[r]) * kInvWScale;      // the weights were packed scaled by 2^10
+          for (int r = 0; r < 4; ++r) v[r] = ((acc[mt][0][r] + s1[r]) + s2[r]) * out_scale;      // the weights were packed scaled by 2^10 (and the input by in_scale)
           *(lds_q *)(po + (mt << 4)) = v;
         }
       }
@@ -464,9 +467,10 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
         f16x8 hi, lo;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-          const _Float16 hh = static_cast<_Float16>(v[j][c]);
+          const float sv = v[j][c] * in_scale;
+          const _Float16 hh = static_cast<_Float16>(sv);
           hi[c] = hh;
-          lo[c] = static_cast<_Float16>(v[j][c] - static_cast<float>(hh));
+          lo[c] = static_cast<_Float16>(sv - static_cast<float>(hh));
         }
         put3(imgH, 2 * (p0 + j) + rs, hi, lo);
       }
@@ -498,6 +502,25 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   };
   auto epilogue = [&](int b, const int (&o)[4], int64_t pidx) {
     const lds_f *ptl = (const lds_f *)(smem_h + 2 * ITEM);
+    if constexpr (FUSE == 3) {
+      // no coupling: the logits themselves, pair-compact (B, C, V/2) -- the form the training path differentiates
+      // (nf_conv_last_logits_split16)
+      float *outp = static_cast<float *>(A.out);
+      const int64_t Vh = A.V / 2;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int u = pass * 64 + lane;
+        bool pok;
+        const int64_t pair = pair_of(b, o, pass, pok);
+        if (pok) {
+          float *d = outp + (int64_t(b) * C) * Vh + (pair - int64_t(b) * Vh);
+#pragma unroll
+          for (int c = 0; c < C; ++c) d[int64_t(c) * Vh] = ptl[c * PTS + u];
+        }
+      }
+      (void)pidx;
+      return;
+    }
     double lacc = 0.0;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -601,7 +624,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   }
   int n1b = cb, n1o[4] = {co4[0], co4[1], co4[2], co4[3]};      // item m + 1
   if (n_my > 1) advance(n1b, n1o);
-  prefetch_x(cb, co4);
+  if (FUSE != 3) prefetch_x(cb, co4);
   lds_barrier();                                // P: image 0 ready
   // n_my + 1 rounds, the last one only the epilogue of the last item: ONE copy of the epilogue in the code, so that every
   // item's spline runs through the same instructions whatever its place in the workgroup's sequence.  (With a second,
@@ -610,7 +633,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   for (int m = 0; m <= n_my; ++m) {
     if (m > 0 && !NF_DBG(A, 128)) epilogue(pb, po, int64_t(vb) + int64_t(m - 1) * nb);     // dbg 128: timing ablation
     if (m == n_my) break;
-    prefetch_x(cb, co4);                        // for the epilogue of item m, one iteration from now
+    if (FUSE != 3) prefetch_x(cb, co4);         // for the epilogue of item m, one iteration from now
     // image m+1 goes where image m-1 and then the partial sums of item m-1 were: after the epilogue above, all rows ahead of
     // B1 (they need the whole MFMA phase and the add-up behind it to land)
     const bool more = m + 1 < n_my && !NF_DBG(A, 64);          // dbg 64: timing ablation
@@ -641,7 +664,8 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
 int conv_h_eligible(const ConvArgs &A, int fuse, int64_t *nboxes) {
   using namespace h;
   if (!option(NF_OPT_SPLIT16) || !fuse) return 0;
-  if (A.cin != 8 || A.cout != C || A.P.m != M || A.P.fx || A.P.fy || NF_DBG(A, 15) || NF_STAMPS(A)) return 0;
+  if (A.cin != 8 || A.cout != C || NF_DBG(A, 15) || NF_STAMPS(A)) return 0;
+  if (fuse != 3 && (A.P.m != M || A.P.fx || A.P.fy)) return 0;
   for (int mu = 0; mu < 4; ++mu)
     if (A.k[mu] != 3) return 0;
   if (A.L[3] < 32 || (A.L[3] & 15)) return 0;                // whole or half segments
@@ -683,8 +707,41 @@ int launch_conv_h(const ConvArgs &A0, int64_t B, int fuse, hipStream_t stream, b
     hipLaunchKernelGGL(kern, dim3(unsigned(grid)), dim3(256), lds, stream, A);
     return 1;
   };
+  if (fuse == 3) return segm ? go(&conv_h_kernel<3, true>, lds_bytes<true>()) : go(&conv_h_kernel<3, false>, lds_bytes<false>());
   if (fuse == 1) return segm ? go(&conv_h_kernel<1, true>, lds_bytes<true>()) : go(&conv_h_kernel<1, false>, lds_bytes<false>());
   return segm ? go(&conv_h_kernel<2, true>, lds_bytes<true>()) : go(&conv_h_kernel<2, false>, lds_bytes<false>());
 }
 
 }  // namespace nf
+
+using namespace nf;
+
+// The last conv layer 8 -> 46 of a spline coupling's net at the active sites, on the split-fp16 kernel, with the LOGITS written
+// out pair-compact (B, 46, V/2) instead of consumed by the coupling: the forward pass of a training step, whose autograd
+// differentiates the spline separately (reference: src/nn/scalar/modules.py:120-145 under Fitter.step).  in: fp32 channel
+// planes (B, 8, V) (fastest axis of 32 sites) or, with in_split16, the (B, V, 16) pair tensor; absmax_bits (or NULL): the
+// input is / gets scaled by the matching power of two (nf_absmax_bits), the logits are descaled.  wsplit: NF_WLAYOUT_SPLIT16.
+extern "C" int nf_conv_last_logits_split16(const void *in, int in_split16, const void *wsplit, const void *bias, void *logits,
+                                           int64_t B, const int32_t *lattice, int active_parity, const void *absmax_bits,
+                                           void *stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  NF_REQUIRE(in && wsplit && logits && lattice, "nf_conv_last_logits_split16: NULL pointer");
+  NF_REQUIRE(B >= 0, "nf_conv_last_logits_split16: negative batch");
+  if (B == 0) return NF_OK;
+  ConvArgs A{};
+  A.V = 1;
+  for (int mu = 0; mu < 4; ++mu) { A.L[mu] = lattice[mu]; A.k[mu] = 3; A.V *= lattice[mu]; }
+  A.in = in; A.wfrag = wsplit; A.bias = bias; A.out = logits;
+  A.cin = 8; A.cout = h::C;
+  A.parity = active_parity & 1;
+  A.in_split16 = in_split16 ? 1 : 0;
+  A.gscale_bits = static_cast<const unsigned *>(absmax_bits);
+  const int pr = launch_conv_h(A, B, 3, stream, false);
+  if (pr == 0) {
+    set_error("nf_conv_last_logits_split16: layer not supported (4-D lattice, even extents, fastest axis 32 + 16 n sites; fp32 planes need 32)");
+    return NF_EINVAL;
+  }
+  if (pr == -2) { set_error("nf_conv_last_logits_split16: batch x boxes >= 2^31 work items, split the batch"); return NF_EINVAL; }
+  if (pr != 1) { set_error("nf_conv_last_logits_split16: could not launch the kernel"); return NF_ELAUNCH; }
+  return check_launch("conv split-fp16 logits kernel");
+}

@@ -1740,3 +1740,36 @@ def test_conv_input_grad_split16_vs_autograd(lattice, cout, B, cin):
             tr = _hip.conv_layer(xs.clone().requires_grad_(True), w.to(DEV, torch.float32), bias.to(DEV, torch.float32),
                                  _hip.ACT_CODES[act])
             assert torch.equal(tr.detach(), got_f)
+
+
+@pytest.mark.parametrize("lattice,B", [((2, 2, 4, 32), 3), ((4, 2, 2, 32), 5)])
+def test_conv_last_logits_split16_vs_oracle(lattice, B):
+    """nf_conv_last_logits_split16 (K5h's matrix-core part with the logits written out): the 8 -> 46 layer at the active
+    sites, pair-compact, against the fp64 oracle convolution; inputs in [-1, 1] and far outside (the input is scaled by the
+    power of two of its maximum); and through ConvFn (training), where it is the forward of the compact last layer and the
+    gradients still match autograd through the oracle.  1e-5 of the largest logit."""
+    g = torch.Generator(device='cpu').manual_seed(46)
+    w = 0.1 * torch.randn((46, 8) + (3,) * 4, generator=g, dtype=torch.float64, device='cpu')
+    bias = torch.randn(46, generator=g, dtype=torch.float64, device='cpu')
+    for scale in (1.0, 300.0):
+        x = scale * torch.tanh(torch.randn((B, 8) + lattice, generator=g, dtype=torch.float64, device='cpu'))
+        full = O.circular_conv_direct(x, w, bias)
+        for parity in (0, 1):
+            act_mask = (O.even_odd_mask(lattice, parity=parity) == 1).reshape(-1)
+            want = compact(full.reshape(B, 46, -1), act_mask.to(torch.uint8))
+            got = _hip.conv_last_logits_split16(x.to(DEV, torch.float32), w.to(DEV, torch.float32), bias.to(DEV, torch.float32), parity)
+            assert got is not None and got.shape == want.shape
+            assert float((got.double().cpu() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    # through autograd: forward equals the direct call bit for bit, gradients vs the oracle
+    x = torch.tanh(torch.randn((B, 8) + lattice, generator=g, dtype=torch.float64, device='cpu'))
+    act_mask = (O.even_odd_mask(lattice, parity=0) == 1).reshape(-1)
+    xd, wd, bd = (t.to(DEV, torch.float32).requires_grad_(True) for t in (x, w, bias))
+    out = _hip.conv_layer(xd, wd, bd, 0, compact=True, parity=0)
+    assert torch.equal(out.detach(), _hip.conv_last_logits_split16(xd.detach(), wd.detach(), bd.detach(), 0))
+    go = torch.randn((B, 46) + lattice, generator=g, dtype=torch.float64, device='cpu') * act_mask.reshape((1, 1) + lattice).double()
+    goc = compact(go.reshape(B, 46, -1).to(DEV, torch.float32), act_mask.to(torch.uint8).to(DEV))
+    got = torch.autograd.grad(out, (xd, wd, bd), goc)
+    xo, wo, bo = (t.clone().requires_grad_(True) for t in (x, w, bias))
+    gref = torch.autograd.grad(O.circular_conv_direct(xo, wo, bo), (xo, wo, bo), go)
+    for a_, r_ in zip(got, gref):
+        assert float((a_.double().cpu() - r_).abs().max()) <= 2e-5 * float(r_.abs().max())
