@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NF_VERSION 205 /* 0.2.0 */
+#define NF_VERSION 206 /* 0.2.0 */
 
 /* NF_F16 (nf_rqs_fwd / nf_rqs_inv with knots_len 4/8/16, nf_affine_fwd / nf_affine_inv): x, params and y are IEEE half, the arithmetic is fp32 and
  * log0 / logj are fp32 ("fp16 params / fp32 log-det accumulate", BASELINE config 5). */
@@ -388,6 +388,9 @@ int nf_conv_wgrad(const void *in, const void *gz, void *gw, int64_t B, const int
  * gz scaled by the power of two of *absmax_bits, see nf_absmax_bits) for the lattice networks' shapes: 4-D lattice with 32 sites on
  * the fastest axis, 3^4 kernels, cin 1 or 8, cout <= 48, fp32.  Same gw layout and accumulate-into-gw semantics as
  * nf_conv_wgrad; deterministic (per-workgroup partial matrices in the workspace, summed in a fixed order).
+ * compact_parity < 0: gz is the full-lattice (B, cout, V) tensor; 0 / 1: gz is pair-compact (B, cout, V/2), the cotangent of
+ * an active-site-only layer (coordinate sum == compact_parity mod 2), read as it is -- no expanded copy (same for
+ * nf_planes_to_split16).
  * nf_conv_wgrad_split16_supported says whether a shape qualifies; callers fall back to nf_conv_wgrad otherwise. */
 /* Input gradients of the lattice networks' conv layers on the split-fp16 chain (training).  The gradient w.r.t. the input of
  * a layer with 8 input channels is a convolution of the output cotangent gz (B, C, V) with the flipped, transposed weights:
@@ -398,7 +401,7 @@ int nf_conv_wgrad(const void *in, const void *gz, void *gw, int64_t B, const int
  * the descaled fp32 planes gx (B, 8, V).  The same entry runs a FORWARD 8 -> 8 layer whose output training keeps as planes:
  * activations as an unscaled pair tensor (absmax_bits NULL), bias, act = tanh.  Lattices as nf_conv_split16_supported. */
 int nf_planes_to_split16(const void *gz, void *out16, const void *absmax_bits, int64_t B, int C,
-                         const int32_t *lattice, void *stream);
+                         const int32_t *lattice, int compact_parity, void *stream);
 int nf_conv_dgrad_split16(const void *in16, const void *wsplit, const void *bias, void *gx, int64_t B,
                           const int32_t *lattice, const void *absmax_bits, int accumulate, int act, void *stream);
 
@@ -419,8 +422,8 @@ int nf_expand_pairs(const void *compact, void *full, int64_t rows, const int32_t
 int nf_conv_wgrad_split16_supported(const int32_t *lattice, const int32_t *ksize, int cin, int cout);
 size_t nf_conv_wgrad_split16_workspace(int64_t B, const int32_t *lattice, int cin);
 int nf_conv_wgrad_split16(const void *in, const void *gz, void *gw, int64_t B, const int32_t *lattice,
-                          const int32_t *ksize, int cin, int cout, const void *absmax_bits, void *workspace,
-                          size_t workspace_bytes, void *stream);
+                          const int32_t *ksize, int cin, int cout, const void *absmax_bits, int compact_parity,
+                          void *workspace, size_t workspace_bytes, void *stream);
 /* max |x| of an fp32 tensor of n elements, as the bits of a float in 4 bytes of device memory: what the training kernels
  * (nf_conv_wgrad_split16, nf_planes_to_split16 / nf_conv_dgrad_split16) scale a cotangent by; one pass serves both. */
 int nf_absmax_bits(const void *x, int64_t n, void *bits, void *stream);

@@ -72,14 +72,14 @@ PROTOTYPES = {
     "nf_act_vjp": (_I, [_P, _P, _P, _I64, _I, _I, _P]),
     "nf_conv_wgrad_cols": (_I, [_I, _I]),
     "nf_conv_wgrad": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I, _P]),
-    "nf_planes_to_split16": (_I, [_P, _P, _P, _I64, _I, C.POINTER(C.c_int32), _P]),
+    "nf_planes_to_split16": (_I, [_P, _P, _P, _I64, _I, C.POINTER(C.c_int32), _I, _P]),
     "nf_conv_dgrad_split16": (_I, [_P, _P, _P, _P, _I64, C.POINTER(C.c_int32), _P, _I, _I, _P]),
     "nf_absmax_bits": (_I, [_P, _I64, _P, _P]),
     "nf_conv_last_logits_split16": (_I, [_P, _I, _P, _P, _P, _I64, C.POINTER(C.c_int32), _I, _P, _P]),
     "nf_expand_pairs": (_I, [_P, _P, _I64, C.POINTER(C.c_int32), _I, _I, _P]),
     "nf_conv_wgrad_split16_supported": (_I, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I]),
     "nf_conv_wgrad_split16_workspace": (_SZ, [_I64, C.POINTER(C.c_int32), _I]),
-    "nf_conv_wgrad_split16": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _P, _P, _SZ, _P]),
+    "nf_conv_wgrad_split16": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _P, _I, _P, _SZ, _P]),
     "nf_conv_rqs_supported": (_I, [_I, _I]),
     "nf_conv_last_path": (_I, []),
     "nf_conv_split16_supported": (_I, [_P, _P, _I, _I, _I]),
@@ -787,10 +787,12 @@ def absmax_bits(t):
     return bits
 
 
-def conv_weight_grad(x, gz, ksize, bits=None):
+def conv_weight_grad(x, gz, ksize, bits=None, compact_parity=-1):
     """(grad_weight (cout, cin, *k), grad_bias (cout)) of a circular conv layer from its input x
     (B, cin, *L) and the full-lattice pre-activation cotangent gz (B, cout, *L): nf_conv_wgrad, or nf_conv_wgrad_split16
-    (`bits`: absmax_bits(gz) if the caller has it already)."""
+    (`bits`: absmax_bits(gz) if the caller has it already).  compact_parity 0 / 1: gz is the pair-compact (B, cout, V/2)
+    cotangent of an active-site-only layer; only the split-fp16 kernel reads that form: None is returned when the shape does
+    not qualify (the caller expands gz and calls again)."""
     lib = load()
     B, cin = x.shape[:2]
     cout = gz.shape[1]
@@ -807,6 +809,8 @@ def conv_weight_grad(x, gz, ksize, bits=None):
         buf = torch.zeros(((c1 - c0 + 15) // 16) * 16, ncols, dtype=x.dtype, device=x.device)
         split = (x.dtype == torch.float32 and lib.nf_get_option(OPT_SPLIT16)
                  and lib.nf_conv_wgrad_split16_supported(lat4, k4, cin, c1 - c0))
+        if compact_parity >= 0 and not split:
+            return None
         for b0 in range(0, B, MAX_B):
             b1 = min(B, b0 + MAX_B)
             if split:       # fp16 matrix cores, three products per fp32 product (nf_conv_w.hip)
@@ -815,7 +819,8 @@ def conv_weight_grad(x, gz, ksize, bits=None):
                 if bits is None:
                     bits = absmax_bits(gz)      # (of the whole cotangent: any power of two that fits the maximum will do)
                 _check(lib.nf_conv_wgrad_split16(_ptr(x[b0:b1]), _ptr(part[b0:b1]), _ptr(buf), b1 - b0, lat4, k4, cin,
-                                                 c1 - c0, _ptr(bits), _ptr(ws), ws.numel(), _stream()), "nf_conv_wgrad_split16")
+                                                 c1 - c0, _ptr(bits), int(compact_parity), _ptr(ws), ws.numel(), _stream()),
+                       "nf_conv_wgrad_split16")
             else:
                 _check(lib.nf_conv_wgrad(_ptr(x[b0:b1]), _ptr(part[b0:b1]), _ptr(buf), b1 - b0, lat4, k4, cin,
                                          c1 - c0, _dtype_code(x), _stream()), "nf_conv_wgrad")
@@ -827,29 +832,33 @@ def conv_weight_grad(x, gz, ksize, bits=None):
     return gw, gb
 
 
-def conv_input_grad_split16(gz, wt, bits=None):
+def conv_input_grad_split16(gz, wt, bits=None, compact_parity=-1, lattice=None):
     """Gradient w.r.t. the input of a 3^4 layer with up to 8 input channels on the split-fp16 chain: gz (B, C, *L) fp32 cotangent
     of the layer's pre-activation, wt (cin, C, 3, 3, 3, 3) its weights flipped and transposed.  The C channels go through the
     hidden-layer kernel in groups of 8 (nf_planes_to_split16 + nf_conv_dgrad_split16).  None when the shape does not qualify
     (the caller then runs the fp32 kernel)."""
     lib = load()
     cin = wt.shape[0]                  # channels of the layer's input = of the gradient (fewer than 8: zero weight rows)
-    if (gz.dtype != torch.float32 or gz.dim() != 6 or cin > 8 or tuple(wt.shape[2:]) != (3, 3, 3, 3)
+    if compact_parity < 0:
+        lattice = tuple(gz.shape[2:])
+    if (gz.dtype != torch.float32 or lattice is None or len(lattice) != 4 or cin > 8 or tuple(wt.shape[2:]) != (3, 3, 3, 3)
             or not lib.nf_get_option(OPT_SPLIT16)):
         return None
     B, Cc = gz.shape[:2]
-    lattice = tuple(gz.shape[2:])
     lat4, k4 = _lat4(lattice, (3, 3, 3, 3))
     if not lib.nf_conv_split16_supported(lat4, k4, 8, 8, ACT_CODES['tanh']) or B > 65535:
         return None
     G = (Cc + 7) // 8
-    V = gz[0, 0].numel()
+    V = 1
+    for n in lattice:
+        V *= n
     gz = gz.contiguous()
     g16 = torch.empty((G, B, V, 16), dtype=torch.float16, device=gz.device)
     if bits is None:
         bits = absmax_bits(gz)
-    _check(lib.nf_planes_to_split16(_ptr(gz), _ptr(g16), _ptr(bits), B, Cc, lat4, _stream()), "nf_planes_to_split16")
-    gx = torch.empty((B, 8) + lattice, dtype=torch.float32, device=gz.device)
+    _check(lib.nf_planes_to_split16(_ptr(gz), _ptr(g16), _ptr(bits), B, Cc, lat4, int(compact_parity), _stream()),
+           "nf_planes_to_split16")
+    gx = torch.empty((B, 8) + tuple(lattice), dtype=torch.float32, device=gz.device)
     wpad = wt.new_zeros((8, 8 * G, 3, 3, 3, 3), dtype=torch.float32)
     wpad[:cin, :Cc] = wt.float()
     for g in range(G):
@@ -874,7 +883,7 @@ def conv_hidden_planes_split16(x, weight, bias, act):
     V = x[0, 0].numel()
     x16 = torch.empty((1, B, V, 16), dtype=torch.float16, device=x.device)
     bits = absmax_bits(x)                        # (any input range: the pair tensor is scaled like a cotangent's)
-    _check(lib.nf_planes_to_split16(_ptr(x), _ptr(x16), _ptr(bits), B, 8, lat4, _stream()), "nf_planes_to_split16")
+    _check(lib.nf_planes_to_split16(_ptr(x), _ptr(x16), _ptr(bits), B, 8, lat4, -1, _stream()), "nf_planes_to_split16")
     wsp = pack_conv_weight_split16_two_site(weight.detach().float())
     out = torch.empty_like(x)
     b = None if bias is None else bias.detach().float().contiguous()
@@ -935,21 +944,35 @@ class ConvFn(torch.autograd.Function):
             gz = torch.empty_like(gout)
             _check(lib.nf_act_vjp(_ptr(gout), _ptr(y), _ptr(gz), gout.numel(), ctx.act, _dtype_code(gout),
                                   _stream()), "nf_act_vjp")
-        if ctx.compact:
-            gz = _compact_to_full(gz, x.shape[2:], ctx.parity)
-        gz = gz.reshape((x.shape[0], weight.shape[0]) + tuple(x.shape[2:])).contiguous()
+        lattice = tuple(x.shape[2:])
+        split_ok = gz.dtype == torch.float32 and len(lattice) == 4 and bool(lib.nf_get_option(OPT_SPLIT16))
+        bits = absmax_bits(gz) if split_ok else None
+        want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        kdims = list(range(2, weight.dim()))
+        wt = weight.detach().flip(kdims).transpose(0, 1).contiguous() if ctx.needs_input_grad[0] else None
         gx = gw = gb = None
-        bits = absmax_bits(gz) if (gz.dtype == torch.float32 and gz.dim() == 6 and lib.nf_get_option(OPT_SPLIT16)) else None
-        if ctx.needs_input_grad[0]:
-            kdims = list(range(2, weight.dim()))
-            wt = weight.detach().flip(kdims).transpose(0, 1).contiguous()
-            gx = conv_input_grad_split16(gz, wt, bits)
-            if gx is None:
-                gx = _conv_launch(gz, wt, None, 0, False, 0)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw, gb = conv_weight_grad(x, gz, weight.shape[2:], bits)
-            if not ctx.has_bias:
-                gb = None
+        if ctx.compact and split_ok:
+            # the pair-compact cotangent as it is: the split-fp16 kernels read that form, no expanded copy
+            gzc = gz.reshape(x.shape[0], weight.shape[0], -1).contiguous()
+            if wt is not None:
+                gx = conv_input_grad_split16(gzc, wt, bits, ctx.parity, lattice)
+            if want_w:
+                got = conv_weight_grad(x, gzc, weight.shape[2:], bits, ctx.parity)
+                if got is not None:
+                    gw, gb = got
+        need_full = (wt is not None and gx is None) or (want_w and gw is None)
+        if need_full:
+            if ctx.compact:
+                gz = _compact_to_full(gz, lattice, ctx.parity)
+            gz = gz.reshape((x.shape[0], weight.shape[0]) + lattice).contiguous()
+            if wt is not None and gx is None:
+                gx = conv_input_grad_split16(gz, wt, bits)
+                if gx is None:
+                    gx = _conv_launch(gz, wt, None, 0, False, 0)
+            if want_w and gw is None:
+                gw, gb = conv_weight_grad(x, gz, weight.shape[2:], bits)
+        if not ctx.has_bias:
+            gb = None
         return gx, gw, gb, None, None, None
 
 

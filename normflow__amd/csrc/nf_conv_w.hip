@@ -48,6 +48,7 @@ struct Args {
   int L[4];
   int B, cin, cout, ncols;
   int64_t ncolumns;                           // B L0 L1
+  int gz_compact, parity;                     // gz is pair-compact (B, cout, V/2): the active sites (coordinate sum == parity mod 2) only
 };
 
 extern __shared__ __align__(16) unsigned char smem_w[];
@@ -79,7 +80,7 @@ __device__ __forceinline__ void split4(const float4 v, f16x4 &hi, f16x4 &lo) {
   }
 }
 
-template <int MT, int CIN>
+template <int MT, int CIN, bool GZC>
 __global__ __launch_bounds__(kThreads, 4) void wgrad16_kernel(Args A) {
   constexpr int PLANE = 9 * CIN * RS;           // one x2 plane of the ring: 3 x 3 neighbour rows x channels
   constexpr int NG = CIN == 8 ? 14 : 2;         // column groups of 16: (2 kernel rows x 8 channels) or (16 kernel rows x 1)
@@ -178,7 +179,18 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad16_kernel(Args A) {
       }
     }
   };
+  // gz full (B, cout, V): 8 float4 per (channel, row); pair-compact (B, cout, V/2): 4 float4 = the row's 16 active sites,
+  // written with zeros between them (the active site of pair p of row (x0, x1, x2) is 2p + ((parity + x0 + x1 + x2) & 1))
   auto load_gz = [&](Staged &S, int b, int x0, int x1, int x2) {
+    if constexpr (GZC) {
+      const float *src = A.gz + (int64_t(b) * A.cout * A.V + site_row(x0, x1, x2)) / 2;
+#pragma unroll
+      for (int it = 0; it < (NGV + 1) / 2; ++it) {
+        const int f = lane + 64 * it, co = f >> 2, q4 = f & 3;
+        S.gv[it] = co < A.cout ? *reinterpret_cast<const float4 *>(src + int64_t(co) * (A.V / 2) + 4 * q4) : float4{0.f, 0.f, 0.f, 0.f};
+      }
+      return;
+    }
     const float *src = A.gz + int64_t(b) * A.cout * A.V + site_row(x0, x1, x2);
 #pragma unroll
     for (int it = 0; it < NGV; ++it) {
@@ -186,8 +198,26 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad16_kernel(Args A) {
       S.gv[it] = co < A.cout ? *reinterpret_cast<const float4 *>(src + int64_t(co) * A.V + 4 * q4) : float4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  auto commit_gz = [&](const Staged &S, int buf) {
+  auto commit_gz = [&](const Staged &S, int buf, int off) {
     unsigned char *gb = gbuf + buf * 48 * GS;
+    if constexpr (GZC) {
+#pragma unroll
+      for (int it = 0; it < (NGV + 1) / 2; ++it) {
+        const int f = lane + 64 * it, co = f >> 2, q4 = f & 3;
+        if (co < A.cout) {
+          float4 s = S.gv[it];
+          s.x *= scale; s.y *= scale; s.z *= scale; s.w *= scale;
+          f16x4 hi, lo;
+          split4(s, hi, lo);
+          const _Float16 z = static_cast<_Float16>(0.f);
+          const f16x8 h8 = off ? f16x8{z, hi[0], z, hi[1], z, hi[2], z, hi[3]} : f16x8{hi[0], z, hi[1], z, hi[2], z, hi[3], z};
+          const f16x8 l8 = off ? f16x8{z, lo[0], z, lo[1], z, lo[2], z, lo[3]} : f16x8{lo[0], z, lo[1], z, lo[2], z, lo[3], z};
+          *reinterpret_cast<f16x8 *>(gb + co * GS + 16 * q4) = h8;
+          *reinterpret_cast<f16x8 *>(gb + co * GS + GLO + 16 * q4) = l8;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < NGV; ++it) {
       const int f = lane + 64 * it, co = f >> 3, q4 = f & 7;
@@ -273,7 +303,7 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad16_kernel(Args A) {
         commit_plane(S, lx2);
       }
       load_gz(S, b, x0, x1, 0);
-      commit_gz(S, 0);
+      commit_gz(S, 0, (A.parity + x0 + x1) & 1);
       if (L2 > 1) {
         load_plane(S, b, x0, x1, 2);
         load_gz(S, b, x0, x1, 1);
@@ -282,7 +312,7 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad16_kernel(Args A) {
       for (int t = 0; t < L2; ++t) {
         if (t + 1 < L2) {                         // what was loaded a step ago: plane t + 2, gz row t + 1
           commit_plane(S, t + 2);
-          commit_gz(S, (t + 1) & 1);
+          commit_gz(S, (t + 1) & 1, (A.parity + x0 + x1 + t + 1) & 1);
         }
         if (t + 2 < L2) {                         // lands while the others multiply row t
           load_plane(S, b, x0, x1, t + 3);
@@ -348,7 +378,8 @@ __global__ __launch_bounds__(256) void expand_pairs_kernel(const T *__restrict__
 // fp32 channel planes (B, C, V) -> G = ceil(C / 8) pair tensors (G, B, V, 16 halfs) of 8 channels each (zeros past C), every
 // value multiplied by the power of two of *absmax: the cotangent as the split-fp16 conv kernels read it (nf_conv_dgrad_split16).
 __global__ __launch_bounds__(256) void planes_to_pairs_kernel(const float *__restrict__ src, unsigned char *__restrict__ dst, int64_t B,
-                                                              int C, int64_t V, int L3, const unsigned *absmax) {
+                                                              int C, int64_t V, int L3, const unsigned *absmax, int compact, int parity,
+                                                              int L1, int L2) {
   const float scale = pow2_scale_for(absmax);
   const int G = (C + 7) >> 3;
   const int64_t total = int64_t(G) * B * V;
@@ -356,17 +387,23 @@ __global__ __launch_bounds__(256) void planes_to_pairs_kernel(const float *__res
     const int64_t site = i % V;
     const int64_t gb = i / V;                  // g * B + b
     const int b = int(gb % B), g = int(gb / B);
+    const int64_t row = site / L3;
+    const int x3 = int(site - row * L3);
+    bool live = true;                          // compact input: only the active sites carry a value
+    if (compact) {
+      const int x2 = int(row % L2), x1 = int((row / L2) % L1), x0 = int(row / (int64_t(L2) * L1));
+      live = ((x0 + x1 + x2 + x3) & 1) == parity;
+    }
     f16x8 hi, lo;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int ch = 8 * g + c;
-      const float v = ch < C ? src[(int64_t(b) * C + ch) * V + site] * scale : 0.f;
+      float v = 0.f;
+      if (ch < C && live) v = (compact ? src[(int64_t(b) * C + ch) * (V / 2) + (site >> 1)] : src[(int64_t(b) * C + ch) * V + site]) * scale;
       const _Float16 h = static_cast<_Float16>(v);
       hi[c] = h;
       lo[c] = static_cast<_Float16>(v - static_cast<float>(h));
     }
-    const int64_t row = site / L3;
-    const int x3 = int(site - row * L3);
     unsigned char *d = dst + (gb * V + row * L3) * 32 + pair_row_offset(x3, L3);
     *reinterpret_cast<f16x8 *>(d) = hi;
     *reinterpret_cast<f16x8 *>(d + L3 * 16) = lo;
@@ -409,8 +446,8 @@ extern "C" size_t nf_conv_wgrad_split16_workspace(int64_t B, const int32_t *latt
 }
 
 extern "C" int nf_conv_wgrad_split16(const void *in, const void *gz, void *gw, int64_t B, const int32_t *lattice,
-                                     const int32_t *ksize, int cin, int cout, const void *absmax_bits, void *workspace,
-                                     size_t workspace_bytes, void *stream) {
+                                     const int32_t *ksize, int cin, int cout, const void *absmax_bits, int compact_parity,
+                                     void *workspace, size_t workspace_bytes, void *stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   NF_REQUIRE(in && gz && gw && lattice && ksize, "nf_conv_wgrad_split16: NULL pointer");
   NF_REQUIRE(nf_conv_wgrad_split16_supported(lattice, ksize, cin, cout),
@@ -424,6 +461,8 @@ extern "C" int nf_conv_wgrad_split16(const void *in, const void *gz, void *gw, i
   A.in = static_cast<const float *>(in);
   A.gz = static_cast<const float *>(gz);
   A.B = int(B); A.cin = cin; A.cout = cout;
+  A.gz_compact = compact_parity >= 0 ? 1 : 0;
+  A.parity = compact_parity & 1;
   A.ncols = nf_conv_wgrad_cols(cin, 81);
   A.ncolumns = B * A.L[0] * A.L[1];
   const int grid = wgrad16_grid(A.ncolumns);
@@ -440,11 +479,15 @@ extern "C" int nf_conv_wgrad_split16(const void *in, const void *gz, void *gw, i
   int rc;
   const int MT = (cout + 15) >> 4;
   const size_t lds = size_t(wg::NSLOT) * 9 * cin * wg::RS + 2 * 48 * wg::GS;
+#define NF_W16G(MTV, CINV, GZ)                                                                                         \
+  {                                                                                                                    \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wg::wgrad16_kernel<MTV, CINV, GZ>),                      \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));                                  \
+    hipLaunchKernelGGL((wg::wgrad16_kernel<MTV, CINV, GZ>), dim3(grid), dim3(wg::kThreads), lds, s, A);                \
+  }
 #define NF_W16(MTV, CINV)                                                                                              \
   {                                                                                                                    \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wg::wgrad16_kernel<MTV, CINV>),                          \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));                                  \
-    hipLaunchKernelGGL((wg::wgrad16_kernel<MTV, CINV>), dim3(grid), dim3(wg::kThreads), lds, s, A);                    \
+    if (A.gz_compact) NF_W16G(MTV, CINV, true) else NF_W16G(MTV, CINV, false)                                          \
   }
   if (cin == 8) {
     if (MT == 1) NF_W16(1, 8) else if (MT == 2) NF_W16(2, 8) else NF_W16(3, 8)
@@ -452,6 +495,7 @@ extern "C" int nf_conv_wgrad_split16(const void *in, const void *gz, void *gw, i
     if (MT == 1) NF_W16(1, 1) else if (MT == 2) NF_W16(2, 1) else NF_W16(3, 1)
   }
 #undef NF_W16
+#undef NF_W16G
   rc = check_launch("wgrad16 kernel");
   if (rc) return rc;
   const int nused = 81 * cin + 1;
@@ -498,7 +542,7 @@ extern "C" int nf_absmax_bits(const void *x, int64_t n, void *bits, void *stream
 // fp32 channel planes (B, C, V) as the split-fp16 kernels read them: ceil(C / 8) pair tensors (G, B, V, 16 halfs), multiplied
 // by the power of two that brings the maximum in *absmax_bits to [2^12, 2^13) (absmax_bits NULL: as they are -- activations).
 extern "C" int nf_planes_to_split16(const void *gz, void *out16, const void *absmax_bits, int64_t B, int C,
-                                    const int32_t *lattice, void *stream) {
+                                    const int32_t *lattice, int compact_parity, void *stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   NF_REQUIRE(gz && out16 && lattice, "nf_planes_to_split16: NULL pointer");
   NF_REQUIRE(B >= 0 && C >= 1, "nf_planes_to_split16: bad sizes");
@@ -509,6 +553,7 @@ extern "C" int nf_planes_to_split16(const void *gz, void *out16, const void *abs
   const int64_t want = (total + 255) / 256;
   hipLaunchKernelGGL(wg::planes_to_pairs_kernel, dim3(unsigned(want < 16384 ? want : 16384)), dim3(256), 0, s,
                      static_cast<const float *>(gz), static_cast<unsigned char *>(out16), B, C, V, lattice[3],
-                     static_cast<const unsigned *>(absmax_bits));
+                     static_cast<const unsigned *>(absmax_bits), compact_parity >= 0 ? 1 : 0, compact_parity & 1, lattice[1],
+                     lattice[2]);
   return check_launch("planes to pairs kernel");
 }
