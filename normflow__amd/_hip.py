@@ -832,7 +832,7 @@ def conv_weight_grad(x, gz, ksize, bits=None, compact_parity=-1):
     return gw, gb
 
 
-def conv_input_grad_split16(gz, wt, bits=None, compact_parity=-1, lattice=None):
+def conv_input_grad_split16(gz, wt, bits=None, compact_parity=-1, lattice=None, weight=None):
     """Gradient w.r.t. the input of a 3^4 layer with up to 8 input channels on the split-fp16 chain: gz (B, C, *L) fp32 cotangent
     of the layer's pre-activation, wt (cin, C, 3, 3, 3, 3) its weights flipped and transposed.  The C channels go through the
     hidden-layer kernel in groups of 8 (nf_planes_to_split16 + nf_conv_dgrad_split16).  None when the shape does not qualify
@@ -847,6 +847,8 @@ def conv_input_grad_split16(gz, wt, bits=None, compact_parity=-1, lattice=None):
     B, Cc = gz.shape[:2]
     lat4, k4 = _lat4(lattice, (3, 3, 3, 3))
     if not lib.nf_conv_split16_supported(lat4, k4, 8, 8, ACT_CODES['tanh']) or B > 65535:
+        return None
+    if not _weights_fit_fp16(wt if weight is None else weight):      # (`weight`: the layer's parameter, whose verdict is cached)
         return None
     G = (Cc + 7) // 8
     V = 1
@@ -955,7 +957,7 @@ class ConvFn(torch.autograd.Function):
             # the pair-compact cotangent as it is: the split-fp16 kernels read that form, no expanded copy
             gzc = gz.reshape(x.shape[0], weight.shape[0], -1).contiguous()
             if wt is not None:
-                gx = conv_input_grad_split16(gzc, wt, bits, ctx.parity, lattice)
+                gx = conv_input_grad_split16(gzc, wt, bits, ctx.parity, lattice, weight)
             if want_w:
                 got = conv_weight_grad(x, gzc, weight.shape[2:], bits, ctx.parity)
                 if got is not None:
@@ -966,7 +968,7 @@ class ConvFn(torch.autograd.Function):
                 gz = _compact_to_full(gz, lattice, ctx.parity)
             gz = gz.reshape((x.shape[0], weight.shape[0]) + lattice).contiguous()
             if wt is not None and gx is None:
-                gx = conv_input_grad_split16(gz, wt, bits)
+                gx = conv_input_grad_split16(gz, wt, bits, weight=weight)
                 if gx is None:
                     gx = _conv_launch(gz, wt, None, 0, False, 0)
             if want_w and gw is None:
