@@ -385,7 +385,7 @@ int nf_conv_wgrad(const void *in, const void *gz, void *gw, int64_t B, const int
                   const int32_t *ksize, int cin, int cout, int dtype, void *stream);
 
 /* The same weight gradient on the fp16 matrix cores (every fp32 product as three fp16 products, fp32 accumulation;
- * gz scaled by the power of two of *absmax_bits, see nf_absmax_bits) for the lattice networks' shapes: 4-D lattice with 32 sites on
+ * gz scaled by the power of two of *absmax_bits, see nf_absmax_bits) for the lattice networks' shapes: 4-D lattice with 32 + 16 n sites on
  * the fastest axis, 3^4 kernels, cin 1 or 8, cout <= 48, fp32.  Same gw layout and accumulate-into-gw semantics as
  * nf_conv_wgrad; deterministic (per-workgroup partial matrices in the workspace, summed in a fixed order).
  * compact_parity < 0: gz is the full-lattice (B, cout, V) tensor; 0 / 1: gz is pair-compact (B, cout, V/2), the cotangent of

@@ -897,11 +897,11 @@ def conv_hidden_planes_split16(x, weight, bias, act):
 def conv_last_logits_split16(x, weight, bias, parity):
     """The forward 8 -> 46 layer at the active sites of parity `parity` on the split-fp16 kernel, logits pair-compact
     (B, 46, V/2) -- the form autograd keeps (ConvFn with compact=True): nf_absmax_bits + nf_conv_last_logits_split16.  None
-    when the shape does not qualify (fp32 planes in: a fastest axis of 32 sites)."""
+    when the shape does not qualify (a fastest axis of 32 + 16 n sites; other than 32: through a pair tensor)."""
     lib = load()
     if (x.dtype != torch.float32 or x.dim() != 6 or tuple(weight.shape) != (46, 8, 3, 3, 3, 3) or x.shape[1] != 8
-            or x.shape[-1] != 32 or any(n < 2 or n % 2 for n in x.shape[2:5]) or not lib.nf_get_option(OPT_SPLIT16)
-            or not _weights_fit_fp16(weight)):
+            or x.shape[-1] < 32 or x.shape[-1] % 16 or any(n < 2 or n % 2 for n in x.shape[2:5])
+            or not lib.nf_get_option(OPT_SPLIT16) or not _weights_fit_fp16(weight)):
         return None
     B = x.shape[0]
     lattice = tuple(x.shape[2:])
@@ -911,7 +911,12 @@ def conv_last_logits_split16(x, weight, bias, parity):
     wsp = pack_conv_weight_split16(weight.detach().float())
     b = None if bias is None else bias.detach().float().contiguous()
     out = torch.empty((B, 46, V // 2), dtype=torch.float32, device=x.device)
-    _check(lib.nf_conv_last_logits_split16(_ptr(x), 0, _ptr(wsp), _ptr(b), _ptr(out), B, lat4, int(parity), _ptr(bits),
+    src, is16 = x, 0
+    if lattice[-1] != 32:            # the kernel stages fp32 planes only for whole-row segments: hand it the pair tensor
+        src = torch.empty((1, B, V, 16), dtype=torch.float16, device=x.device)
+        _check(lib.nf_planes_to_split16(_ptr(x), _ptr(src), _ptr(bits), B, 8, lat4, -1, _stream()), "nf_planes_to_split16")
+        is16 = 1
+    _check(lib.nf_conv_last_logits_split16(_ptr(src), is16, _ptr(wsp), _ptr(b), _ptr(out), B, lat4, int(parity), _ptr(bits),
                                            _stream()), "nf_conv_last_logits_split16")
     return out
 

@@ -90,11 +90,13 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad16_kernel(Args A) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, kq = lane >> 4;
   const int L0 = A.L[0], L1 = A.L[1], L2 = A.L[2];
-  const int64_t rowsz = 32;                     // sites of a lattice row (the fastest axis)
+  const int L3 = A.L[3], NSEG = (L3 + 31) >> 5; // a lattice row is cut into segments of 32 sites (the last one may hold 16)
+  const int64_t rowsz = L3;                     // sites of a lattice row (the fastest axis)
   const float scale = gz_scale(A.absmax);
 
   // zero the gz images once: channels cout .. 47 are never written
   for (int i = threadIdx.x; i < 2 * 48 * GS / 4; i += kThreads) reinterpret_cast<unsigned *>(gbuf)[i] = 0u;
+  for (int i = threadIdx.x; i < NSLOT * PLANE / 4; i += kThreads) reinterpret_cast<unsigned *>(ring)[i] = 0u;      // (a partial segment's tail is multiplied by zeros: keep it finite)
 
   // ---- multiplying waves: per-lane constants of their two groups
   int boff[2] = {0, 0}, bj2[2] = {0, 0};
@@ -129,18 +131,29 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad16_kernel(Args A) {
     x2 = x2 < 0 ? x2 + L2 : (x2 >= L2 ? x2 - L2 : x2);
     return ((int64_t(x0) * L1 + x1) * L2 + x2) * rowsz;
   };
-  auto put_row = [&](unsigned char *img, int q4, const float4 v) {       // sites 4 q4 .. 4 q4 + 3 of a row image, with the wrapped copies
+  // sites 4 q4 .. 4 q4 + 3 of a segment's row image (zeros past the segment's nv sites) with the neighbour site on either side:
+  // for a whole-row segment (L3 = 32) the row's own ends, held by the lanes q4 = 7 / 0; otherwise `hal`, which the lanes
+  // q4 = 0 (left neighbour) and q4 = 7 (right neighbour) loaded
+  auto put_row = [&](unsigned char *img, int q4, float4 v, float hal, int nv) {
+    if (4 * q4 >= nv) v = float4{0.f, 0.f, 0.f, 0.f};
     f16x4 hi, lo;
     split4(v, hi, lo);
     *reinterpret_cast<f16x4 *>(img + (8 + 4 * q4) * 2) = hi;
     *reinterpret_cast<f16x4 *>(img + LO + (8 + 4 * q4) * 2) = lo;
-    if (q4 == 0) {
-      *reinterpret_cast<_Float16 *>(img + 40 * 2) = hi[0];
-      *reinterpret_cast<_Float16 *>(img + LO + 40 * 2) = lo[0];
-    }
-    if (q4 == 7) {
-      *reinterpret_cast<_Float16 *>(img + 7 * 2) = hi[3];
-      *reinterpret_cast<_Float16 *>(img + LO + 7 * 2) = lo[3];
+    if (L3 == 32) {
+      if (q4 == 0) {
+        *reinterpret_cast<_Float16 *>(img + 40 * 2) = hi[0];
+        *reinterpret_cast<_Float16 *>(img + LO + 40 * 2) = lo[0];
+      }
+      if (q4 == 7) {
+        *reinterpret_cast<_Float16 *>(img + 7 * 2) = hi[3];
+        *reinterpret_cast<_Float16 *>(img + LO + 7 * 2) = lo[3];
+      }
+    } else if (q4 == 0 || q4 == 7) {
+      const _Float16 h = static_cast<_Float16>(hal), l = static_cast<_Float16>(hal - static_cast<float>(h));
+      const int at = q4 == 0 ? 7 : 8 + nv;
+      *reinterpret_cast<_Float16 *>(img + at * 2) = h;
+      *reinterpret_cast<_Float16 *>(img + LO + at * 2) = l;
     }
   };
   // A plane / a gz row travel in two steps, global -> registers and registers -> LDS images, so that the stager can have the
@@ -148,20 +161,31 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad16_kernel(Args A) {
   // row, taken in line, was most of the kernel's time).
   constexpr int NPV = CIN == 8 ? 9 : 2;         // float4 per lane of a plane
   constexpr int NGV = (16 * MT * 8 + 63) / 64;  // ... of a gz row
-  struct Staged { float4 pv[NPV]; float4 gv[NGV]; };
+  struct Staged { float4 pv[NPV]; float ph[NPV]; float4 gv[NGV]; };
+  int seg0 = 0, nv = 32;                        // the open column's segment: first site, sites (32 or 16)
   auto load_plane = [&](Staged &S, int b, int x0, int x1, int lx2) {      // logical plane lx2 (-1 .. L2) of column (b, x0, x1)
     const float *src = A.in + int64_t(b) * CIN * A.V;
+    auto one = [&](const float *rowp, int q4, float4 &v, float &hal) {
+      v = 4 * q4 < nv ? *reinterpret_cast<const float4 *>(rowp + seg0 + 4 * q4) : float4{0.f, 0.f, 0.f, 0.f};
+      hal = 0.f;
+      if (L3 != 32 && (q4 == 0 || q4 == 7)) {
+        int xs = q4 == 0 ? seg0 - 1 : seg0 + nv;
+        xs = xs < 0 ? xs + L3 : (xs >= L3 ? xs - L3 : xs);
+        hal = rowp[xs];
+      }
+    };
     if (CIN == 8) {
       const int ci = lane >> 3, q4 = lane & 7;
 #pragma unroll
       for (int rs = 0; rs < 9; ++rs)
-        S.pv[rs] = *reinterpret_cast<const float4 *>(src + int64_t(ci) * A.V + site_row(x0 + rs / 3 - 1, x1 + rs % 3 - 1, lx2) + 4 * q4);
+        one(src + int64_t(ci) * A.V + site_row(x0 + rs / 3 - 1, x1 + rs % 3 - 1, lx2), q4, S.pv[rs], S.ph[rs]);
     } else {
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int f = lane + 64 * it, rs = f >> 3, q4 = f & 7;
-        S.pv[it] = f < 72 ? *reinterpret_cast<const float4 *>(src + site_row(x0 + rs / 3 - 1, x1 + rs % 3 - 1, lx2) + 4 * q4)
-                          : float4{0.f, 0.f, 0.f, 0.f};
+        S.pv[it] = float4{0.f, 0.f, 0.f, 0.f};
+        S.ph[it] = 0.f;
+        if (f < 72) one(src + site_row(x0 + rs / 3 - 1, x1 + rs % 3 - 1, lx2), q4, S.pv[it], S.ph[it]);
       }
     }
   };
@@ -170,12 +194,12 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad16_kernel(Args A) {
     if (CIN == 8) {
       const int ci = lane >> 3, q4 = lane & 7;
 #pragma unroll
-      for (int rs = 0; rs < 9; ++rs) put_row(pl + (rs * CIN + ci) * RS, q4, S.pv[rs]);
+      for (int rs = 0; rs < 9; ++rs) put_row(pl + (rs * CIN + ci) * RS, q4, S.pv[rs], S.ph[rs], nv);
     } else {
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int f = lane + 64 * it, rs = f >> 3, q4 = f & 7;
-        if (f < 72) put_row(pl + rs * RS, q4, S.pv[it]);
+        if (f < 72) put_row(pl + rs * RS, q4, S.pv[it], S.ph[it], nv);
       }
     }
   };
@@ -183,19 +207,21 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad16_kernel(Args A) {
   // written with zeros between them (the active site of pair p of row (x0, x1, x2) is 2p + ((parity + x0 + x1 + x2) & 1))
   auto load_gz = [&](Staged &S, int b, int x0, int x1, int x2) {
     if constexpr (GZC) {
-      const float *src = A.gz + (int64_t(b) * A.cout * A.V + site_row(x0, x1, x2)) / 2;
+      const float *src = A.gz + (int64_t(b) * A.cout * A.V + site_row(x0, x1, x2) + seg0) / 2;
 #pragma unroll
       for (int it = 0; it < (NGV + 1) / 2; ++it) {
         const int f = lane + 64 * it, co = f >> 2, q4 = f & 3;
-        S.gv[it] = co < A.cout ? *reinterpret_cast<const float4 *>(src + int64_t(co) * (A.V / 2) + 4 * q4) : float4{0.f, 0.f, 0.f, 0.f};
+        S.gv[it] = (co < A.cout && 8 * q4 < nv) ? *reinterpret_cast<const float4 *>(src + int64_t(co) * (A.V / 2) + 4 * q4)
+                                                : float4{0.f, 0.f, 0.f, 0.f};
       }
       return;
     }
-    const float *src = A.gz + int64_t(b) * A.cout * A.V + site_row(x0, x1, x2);
+    const float *src = A.gz + int64_t(b) * A.cout * A.V + site_row(x0, x1, x2) + seg0;
 #pragma unroll
     for (int it = 0; it < NGV; ++it) {
       const int f = lane + 64 * it, co = f >> 3, q4 = f & 7;
-      S.gv[it] = co < A.cout ? *reinterpret_cast<const float4 *>(src + int64_t(co) * A.V + 4 * q4) : float4{0.f, 0.f, 0.f, 0.f};
+      S.gv[it] = (co < A.cout && 4 * q4 < nv) ? *reinterpret_cast<const float4 *>(src + int64_t(co) * A.V + 4 * q4)
+                                              : float4{0.f, 0.f, 0.f, 0.f};
     }
   };
   auto commit_gz = [&](const Staged &S, int buf, int off) {
@@ -283,7 +309,11 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad16_kernel(Args A) {
   };
 
   __syncthreads();
-  auto column_of = [&](int64_t col, int &b, int &x0, int &x1) {
+  auto column_of = [&](int64_t col, int &b, int &x0, int &x1) {      // (the segment is the fastest index)
+    const int hs = int(col % NSEG);
+    col /= NSEG;
+    seg0 = 32 * hs;
+    nv = L3 - seg0 < 32 ? L3 - seg0 : 32;
     b = int(col / (int64_t(L0) * L1));
     const int rem = int(col - int64_t(b) * L0 * L1);
     x0 = rem / L1;
@@ -432,7 +462,7 @@ extern "C" int nf_conv_wgrad_split16_supported(const int32_t *lattice, const int
   if (!lattice || !ksize) return 0;
   for (int mu = 0; mu < 4; ++mu)
     if (ksize[mu] != 3 || lattice[mu] < 1) return 0;
-  if (lattice[3] != 32) return 0;
+  if (lattice[3] < 32 || (lattice[3] & 15)) return 0;       // segments of 32 sites, the last one 32 or 16
   if (cin != 1 && cin != 8) return 0;
   return cout >= 1 && cout <= 48;
 }
@@ -441,7 +471,7 @@ static int wgrad16_grid(int64_t ncolumns) { return int(ncolumns < 512 ? ncolumns
 
 extern "C" size_t nf_conv_wgrad_split16_workspace(int64_t B, const int32_t *lattice, int cin) {
   if (!lattice) return 0;
-  const int64_t ncolumns = B * lattice[0] * lattice[1];
+  const int64_t ncolumns = B * lattice[0] * lattice[1] * ((lattice[3] + 31) / 32);
   return 256 + size_t(wgrad16_grid(ncolumns)) * 48 * size_t(nf_conv_wgrad_cols(cin, 81)) * sizeof(float);
 }
 
@@ -451,7 +481,7 @@ extern "C" int nf_conv_wgrad_split16(const void *in, const void *gz, void *gw, i
   hipStream_t s = static_cast<hipStream_t>(stream);
   NF_REQUIRE(in && gz && gw && lattice && ksize, "nf_conv_wgrad_split16: NULL pointer");
   NF_REQUIRE(nf_conv_wgrad_split16_supported(lattice, ksize, cin, cout),
-             "nf_conv_wgrad_split16: needs a 4-D lattice with 32 sites on the fastest axis, 3^4 kernels, cin 1 or 8, cout <= 48");
+             "nf_conv_wgrad_split16: needs a 4-D lattice with 32 + 16 n sites on the fastest axis, 3^4 kernels, cin 1 or 8, cout <= 48");
   NF_REQUIRE(B >= 0 && B < (int64_t(1) << 24), "nf_conv_wgrad_split16: bad batch");
   if (B == 0) return NF_OK;
   wg::Args A{};
@@ -464,7 +494,7 @@ extern "C" int nf_conv_wgrad_split16(const void *in, const void *gz, void *gw, i
   A.gz_compact = compact_parity >= 0 ? 1 : 0;
   A.parity = compact_parity & 1;
   A.ncols = nf_conv_wgrad_cols(cin, 81);
-  A.ncolumns = B * A.L[0] * A.L[1];
+  A.ncolumns = B * A.L[0] * A.L[1] * ((A.L[3] + 31) / 32);
   const int grid = wgrad16_grid(A.ncolumns);
   const size_t need = nf_conv_wgrad_split16_workspace(B, lattice, cin);
   if (!workspace || workspace_bytes < need) {

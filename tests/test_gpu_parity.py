@@ -1635,7 +1635,8 @@ def test_hack_and_propagate_density(dtype):
 
 
 @pytest.mark.parametrize("lattice,cin,cout,B", [((2, 3, 4, 32), 8, 46, 3), ((2, 2, 2, 32), 1, 8, 5), ((4, 2, 2, 32), 8, 8, 2),
-                                                ((1, 1, 3, 32), 8, 22, 4), ((3, 2, 1, 32), 1, 8, 2)])
+                                                ((1, 1, 3, 32), 8, 22, 4), ((3, 2, 1, 32), 1, 8, 2), ((2, 2, 3, 48), 8, 46, 2),
+                                                ((2, 1, 2, 64), 8, 8, 3), ((1, 2, 2, 48), 1, 8, 2), ((2, 2, 1, 96), 8, 14, 1)])
 def test_conv_wgrad_split16_kernel_vs_autograd(lattice, cin, cout, B):
     """nf_conv_wgrad_split16 (nf_conv_w.hip): grad_weight and grad_bias of a 3^4 circular conv layer on the fp16 matrix cores
     (three fp16 products per fp32 product, gz scaled into fp16's range) against autograd through the fp64 oracle
@@ -1742,7 +1743,7 @@ def test_conv_input_grad_split16_vs_autograd(lattice, cout, B, cin):
             assert torch.equal(tr.detach(), got_f)
 
 
-@pytest.mark.parametrize("lattice,B", [((2, 2, 4, 32), 3), ((4, 2, 2, 32), 5)])
+@pytest.mark.parametrize("lattice,B", [((2, 2, 4, 32), 3), ((4, 2, 2, 32), 5), ((2, 2, 2, 48), 2), ((2, 4, 2, 64), 1)])
 def test_conv_last_logits_split16_vs_oracle(lattice, B):
     """nf_conv_last_logits_split16 (K5h's matrix-core part with the logits written out): the 8 -> 46 layer at the active
     sites, pair-compact, against the fp64 oracle convolution; inputs in [-1, 1] and far outside (the input is scaled by the
