@@ -80,7 +80,7 @@ __device__ __forceinline__ void split4(const float4 v, f16x4 &hi, f16x4 &lo) {
   }
 }
 
-template <int MT, int CIN, bool GZC>
+template <int MT, int CIN, bool GZC, bool SEGM>
 __global__ __launch_bounds__(kThreads, 4) void wgrad16_kernel(Args A) {
   constexpr int PLANE = 9 * CIN * RS;           // one x2 plane of the ring: 3 x 3 neighbour rows x channels
   constexpr int NG = CIN == 8 ? 14 : 2;         // column groups of 16: (2 kernel rows x 8 channels) or (16 kernel rows x 1)
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad16_kernel(Args A) {
     split4(v, hi, lo);
     *reinterpret_cast<f16x4 *>(img + (8 + 4 * q4) * 2) = hi;
     *reinterpret_cast<f16x4 *>(img + LO + (8 + 4 * q4) * 2) = lo;
-    if (L3 == 32) {
+    if constexpr (!SEGM) {
       if (q4 == 0) {
         *reinterpret_cast<_Float16 *>(img + 40 * 2) = hi[0];
         *reinterpret_cast<_Float16 *>(img + LO + 40 * 2) = lo[0];
@@ -165,13 +165,18 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad16_kernel(Args A) {
   int seg0 = 0, nv = 32;                        // the open column's segment: first site, sites (32 or 16)
   auto load_plane = [&](Staged &S, int b, int x0, int x1, int lx2) {      // logical plane lx2 (-1 .. L2) of column (b, x0, x1)
     const float *src = A.in + int64_t(b) * CIN * A.V;
+    // (straight-line loads: with a load under a lane-dependent condition the compiler waits for each row's data before it
+    //  asks for the next row's, and the staging wave lives on having all of a step's loads in flight together)
+    int xs = (lane & 7) == 0 ? seg0 - 1 : seg0 + nv;      // the neighbour site the lanes q4 = 0 / 7 bring (any valid site for the others)
+    xs = xs < 0 ? xs + L3 : (xs >= L3 ? xs - L3 : xs);
+    const int q4c = 4 * (lane & 7) < nv ? (lane & 7) : 0; // (a partial segment's idle lanes re-read its first quad)
     auto one = [&](const float *rowp, int q4, float4 &v, float &hal) {
-      v = 4 * q4 < nv ? *reinterpret_cast<const float4 *>(rowp + seg0 + 4 * q4) : float4{0.f, 0.f, 0.f, 0.f};
-      hal = 0.f;
-      if (L3 != 32 && (q4 == 0 || q4 == 7)) {
-        int xs = q4 == 0 ? seg0 - 1 : seg0 + nv;
-        xs = xs < 0 ? xs + L3 : (xs >= L3 ? xs - L3 : xs);
+      if constexpr (SEGM) {
+        v = *reinterpret_cast<const float4 *>(rowp + seg0 + 4 * q4c);
         hal = rowp[xs];
+      } else {
+        v = *reinterpret_cast<const float4 *>(rowp + 4 * q4);
+        hal = 0.f;
       }
     };
     if (CIN == 8) {
@@ -182,10 +187,8 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad16_kernel(Args A) {
     } else {
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
-        const int f = lane + 64 * it, rs = f >> 3, q4 = f & 7;
-        S.pv[it] = float4{0.f, 0.f, 0.f, 0.f};
-        S.ph[it] = 0.f;
-        if (f < 72) one(src + site_row(x0 + rs / 3 - 1, x1 + rs % 3 - 1, lx2), q4, S.pv[it], S.ph[it]);
+        const int f = lane + 64 * it, rs = f < 72 ? f >> 3 : 8, q4 = f & 7;      // (lanes past the 72 quads re-read row 8)
+        one(src + site_row(x0 + rs / 3 - 1, x1 + rs % 3 - 1, lx2), q4, S.pv[it], S.ph[it]);
       }
     }
   };
@@ -211,8 +214,8 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad16_kernel(Args A) {
 #pragma unroll
       for (int it = 0; it < (NGV + 1) / 2; ++it) {
         const int f = lane + 64 * it, co = f >> 2, q4 = f & 3;
-        S.gv[it] = (co < A.cout && 8 * q4 < nv) ? *reinterpret_cast<const float4 *>(src + int64_t(co) * (A.V / 2) + 4 * q4)
-                                                : float4{0.f, 0.f, 0.f, 0.f};
+        const int coc = co < A.cout ? co : A.cout - 1, qc = 8 * q4 < nv ? q4 : 0;      // (straight-line: idle lanes re-read valid data)
+        S.gv[it] = *reinterpret_cast<const float4 *>(src + int64_t(coc) * (A.V / 2) + 4 * qc);
       }
       return;
     }
@@ -220,8 +223,8 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad16_kernel(Args A) {
 #pragma unroll
     for (int it = 0; it < NGV; ++it) {
       const int f = lane + 64 * it, co = f >> 3, q4 = f & 7;
-      S.gv[it] = (co < A.cout && 4 * q4 < nv) ? *reinterpret_cast<const float4 *>(src + int64_t(co) * A.V + 4 * q4)
-                                              : float4{0.f, 0.f, 0.f, 0.f};
+      const int coc = co < A.cout ? co : A.cout - 1, qc = 4 * q4 < nv ? q4 : 0;
+      S.gv[it] = *reinterpret_cast<const float4 *>(src + int64_t(coc) * A.V + 4 * qc);
     }
   };
   auto commit_gz = [&](const Staged &S, int buf, int off) {
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad16_kernel(Args A) {
       for (int it = 0; it < (NGV + 1) / 2; ++it) {
         const int f = lane + 64 * it, co = f >> 2, q4 = f & 3;
         if (co < A.cout) {
-          float4 s = S.gv[it];
+          float4 s = 8 * q4 < nv ? S.gv[it] : float4{0.f, 0.f, 0.f, 0.f};
           s.x *= scale; s.y *= scale; s.z *= scale; s.w *= scale;
           f16x4 hi, lo;
           split4(s, hi, lo);
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad16_kernel(Args A) {
     for (int it = 0; it < NGV; ++it) {
       const int f = lane + 64 * it, co = f >> 3, q4 = f & 7;
       if (co < A.cout) {
-        float4 s = S.gv[it];
+        float4 s = 4 * q4 < nv ? S.gv[it] : float4{0.f, 0.f, 0.f, 0.f};
         s.x *= scale; s.y *= scale; s.z *= scale; s.w *= scale;
         f16x4 hi, lo;
         split4(s, hi, lo);
@@ -425,11 +428,16 @@ __global__ __launch_bounds__(256) void planes_to_pairs_kernel(const float *__res
       live = ((x0 + x1 + x2 + x3) & 1) == parity;
     }
     f16x8 hi, lo;
+    const int64_t per = compact ? V / 2 : V, at = compact ? (site >> 1) : site;
+    float raw[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {             // (straight-line loads: channels past C re-read the last one)
+      const int ch = 8 * g + c < C ? 8 * g + c : C - 1;
+      raw[c] = src[(int64_t(b) * C + ch) * per + at];
+    }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const int ch = 8 * g + c;
-      float v = 0.f;
-      if (ch < C && live) v = (compact ? src[(int64_t(b) * C + ch) * (V / 2) + (site >> 1)] : src[(int64_t(b) * C + ch) * V + site]) * scale;
+      const float v = (8 * g + c < C && live) ? raw[c] * scale : 0.f;
       const _Float16 h = static_cast<_Float16>(v);
       hi[c] = h;
       lo[c] = static_cast<_Float16>(v - static_cast<float>(h));
@@ -509,11 +517,15 @@ extern "C" int nf_conv_wgrad_split16(const void *in, const void *gz, void *gw, i
   int rc;
   const int MT = (cout + 15) >> 4;
   const size_t lds = size_t(wg::NSLOT) * 9 * cin * wg::RS + 2 * 48 * wg::GS;
+#define NF_W16S(MTV, CINV, GZ, SG)                                                                                     \
+  {                                                                                                                    \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wg::wgrad16_kernel<MTV, CINV, GZ, SG>),                  \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));                                  \
+    hipLaunchKernelGGL((wg::wgrad16_kernel<MTV, CINV, GZ, SG>), dim3(grid), dim3(wg::kThreads), lds, s, A);            \
+  }
 #define NF_W16G(MTV, CINV, GZ)                                                                                         \
   {                                                                                                                    \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wg::wgrad16_kernel<MTV, CINV, GZ>),                      \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));                                  \
-    hipLaunchKernelGGL((wg::wgrad16_kernel<MTV, CINV, GZ>), dim3(grid), dim3(wg::kThreads), lds, s, A);                \
+    if (A.L[3] != 32) NF_W16S(MTV, CINV, GZ, true) else NF_W16S(MTV, CINV, GZ, false)                                  \
   }
 #define NF_W16(MTV, CINV)                                                                                              \
   {                                                                                                                    \
@@ -526,6 +538,7 @@ extern "C" int nf_conv_wgrad_split16(const void *in, const void *gz, void *gw, i
   }
 #undef NF_W16
 #undef NF_W16G
+#undef NF_W16S
   rc = check_launch("wgrad16 kernel");
   if (rc) return rc;
   const int nused = 81 * cin + 1;
