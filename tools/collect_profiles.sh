@@ -1,0 +1,20 @@
+# Run on the GPU box from the repo root (gpurun -- bash tools/collect_profiles.sh): the bench line, the bench under
+# rocprofv3 --kernel-trace --stats, separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ counters) over tools/kbench.py, the PMC
+# summary bench.py quotes its roofline.traffic from, and the batch-128 bench.  Then: python tools/install_profiles.py
+set -e
+P=gpurun_out/r02p
+mkdir -p $P
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python bench.py --steps 3 --warmup 1 > $P/bench.json 2> $P/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $P/bench_under_rocprof.json 2> $P/trace.err
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $P/$c -o run -- python3 tools/kbench.py --reps 2 > $P/$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $P/${c}_k2 -o run -- python3 tools/kbench.py --only k2 --reps 3 > $P/${c}_k2.log 2>&1
+done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU --kernel-trace --output-format csv -d $P/sq -o run -- python3 tools/kbench.py --reps 2 > $P/sq.log 2>&1
+for f in $P/FETCH_SIZE_k2/*/*counter_collection.csv $P/FETCH_SIZE_k2/*counter_collection.csv; do [ -f "$f" ] && cp $f $P/FETCH_SIZE/k2_counter_collection.csv; done
+for f in $P/WRITE_SIZE_k2/*/*counter_collection.csv $P/WRITE_SIZE_k2/*counter_collection.csv; do [ -f "$f" ] && cp $f $P/WRITE_SIZE/k2_counter_collection.csv; done
+python tools/make_pmc_profile.py --fetch $P/FETCH_SIZE --write $P/WRITE_SIZE --sq $P/sq --out $P/r02_pmc_kernels.json --note "round 2 final kernels (conv_c2 / conv_g2 / conv_h with LDS-DMA staging and the indexed spline pass); kbench at the pipeline's 256-sample slab; K2 at its 33-sample slab"
+python bench.py --steps 3 --warmup 1 --batch 128 --no-cpu-baseline > $P/bench_batch128.json 2> $P/bench128.err || true
+find $P -name "*kernel_stats.csv" | head -3
+tail -c 400 $P/bench.json
