@@ -158,7 +158,8 @@ def time_rqs_kernel(cpl, lattice, m, dev, reps, layout_pair):
 def _pipeline_slab(cpl, lattice, batch):
     net = cpl.nets[0]
     hidden = max(net.conv_kwargs['hidden_sizes'])
-    return max(1, min(batch, cpl.HIDDEN_SLAB_BYTES // (hidden * _vol(lattice) * 4))), hidden
+    from normflow__amd.nn.scalar import couplings_
+    return max(1, min(batch, couplings_.HIDDEN_SLAB_BYTES // (hidden * _vol(lattice) * 4))), hidden
 
 
 def time_fused_last_layer(cpl, lattice, m, dev, reps, batch):
@@ -344,9 +345,19 @@ def main():
     rehearsal = os.environ.get("NF_BENCH_REHEARSAL", "0") == "1"
     dev = torch.device("cuda", 0 if rehearsal else local)
     torch.cuda.set_device(dev)
+    if a.scaling in ("strong", "both") and world > 1 and a.batch % world:
+        # refuse before any rank touches the GPU: a strong-scaling leg cuts ONE global batch into equal shards
+        print(f"bench.py: the strong-scaling leg cuts the global batch {a.batch} into {world} equal shards, and {a.batch} is not "
+              f"a multiple of {world}; pass --batch as a multiple of --gpus or --scaling weak", file=sys.stderr)
+        sys.exit(2)
+    ranks_info = None
     if world > 1:
         dist.init_process_group(backend="gloo" if rehearsal else "nccl", rank=rank, world_size=world)   # "nccl" = RCCL
         assert dist.get_world_size() == a.gpus
+        mine = {"rank": rank, "device": f"cuda:{dev.index}", "name": torch.cuda.get_device_name(dev)}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        ranks_info = {"rccl_world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": gathered}
     import normflow__amd  # noqa: F401
     from normflow__amd import _hip
     lattice = tuple(int(s) for s in a.lattice.split(","))
@@ -405,8 +416,7 @@ def main():
         if world == 1 and "weak" in legs:
             legs["strong"] = dict(legs["weak"])
         else:
-            per = a.batch // world
-            assert per >= 1 and per * world == a.batch, "the global batch must divide over the ranks"
+            per = a.batch // world           # divisibility was checked before the process group came up
             el = timed(x[:per], a.steps, a.warmup)
             legs["strong"] = {"value": a.batch * a.steps / el, "ms_per_step": 1e3 * el / a.steps, "global_batch": a.batch,
                               "batch_per_gpu": per}
@@ -486,6 +496,8 @@ def main():
             "roofline_hbm_kernel": hbm_obj,
             "kernel_src_sha": kernel_src_sha(),
         }
+        if ranks_info is not None:
+            line.update(ranks_info)
         for name, leg in legs.items():
             if name != main_leg:
                 line[name] = dict(leg, scaling=name)

@@ -173,6 +173,18 @@ int nf_rqs_inv_sites(const void *y, const void *params, const uint8_t *mask, con
 int nf_rqs_knots(const void *params, void *knots, int64_t B, int64_t V, const nf_rqs_opts *opts,
                  int dtype, void *stream);
 
+/* ---- K2e: a spline from explicit knot tensors ------------------------------------
+ * The reference's generic spline object RQSpline(knots_x, knots_y, knots_d) = Pade22Spline
+ * (src/lib/spline/spline.py:39-68; forward / backward :87-123; searchsorted + clamp :154-172;
+ * segment function :185-220; inverse :222-287, with the stable root of App. A #2).
+ * v, out, deriv: (B, V) of dtype (deriv may be NULL).  A knot tensor is (B, K, V) planes, or a
+ * shared vector of K entries when its shared_* flag is set (the reference's 1-D knots).  Knots
+ * are evaluated as given (already augmented for extrapolation; values outside reuse the end
+ * segments).  inverse: out = x(v), deriv = dx/dy = 1/g.  NF_F32 / NF_F64, B <= 65535. */
+int nf_spline_eval(const void *v, const void *knots_x, const void *knots_y, const void *knots_d,
+                   void *out, void *deriv, int64_t B, int64_t V, int K, int shared_x, int shared_y,
+                   int shared_d, int inverse, int dtype, void *stream);
+
 /* ---- K1: affine / shift coupling --------------------------------------------
  * Replaces couplings_.py:123-139 (affine: chunk, 2 purify, abs, exp, fma, sum)
  * and :110-116 (shift).  params is (B, 2, .) = (t, s) for affine, (B, 1, .) = t
@@ -354,6 +366,10 @@ int nf_normal_logprob(const void *x, const void *loc, const void *scale, void *l
                       void *workspace, size_t workspace_bytes, int dtype, void *stream);
 int nf_normal_logprob_vjp(const void *x, const void *loc, const void *scale, const void *grad_logp,
                           void *grad_x, int64_t B, int64_t V, int dtype, void *stream);
+/* Folded (XOR) into the high key word of nf_normal_sample's Philox generator: separates its streams from torch's own
+ * Philox kernels, which key on the bare seed. */
+#define NF_PHILOX_KEY_DOMAIN 0x6e66686bu   /* 'nfhk' */
+
 /* nf_normal_sample: Prior.sample_ for a NormalPrior (src/prior/prior.py:26-29 with :30-36 and :92-101) in ONE launch:
  * x[b, i] = loc[i] + scale[i] z[b, i] with z standard normal, and logr[b] = sum_i [-z^2/2 - log scale[i] - log sqrt(2 pi)]
  * accumulated from the z still in registers (the reference draws, then re-reads the field for log_prob, then sums).

@@ -8,6 +8,7 @@ stream and autograd bookkeeping only.
 import ctypes as C
 import os
 import threading
+import weakref
 
 import torch
 
@@ -52,6 +53,7 @@ PROTOTYPES = {
     "nf_rqs_fwd_sites": (_I, _SITES_ARGS),
     "nf_rqs_inv_sites": (_I, _SITES_ARGS),
     "nf_rqs_knots": (_I, [_P, _P, _I64, _I64, C.POINTER(RqsOpts), _I, _P]),
+    "nf_spline_eval": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _I, _I, _I, _I, _P]),
     "nf_rqs_fwd_vjp": (_I, _VJP_ARGS),
     "nf_rqs_inv_vjp": (_I, _VJP_ARGS),
     "nf_affine_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _P, _SZ, _I, _P]),
@@ -256,6 +258,51 @@ def rqs_sites(v, params, mask, log0, opts, inverse, mode=SITES_LOG):
                   _ptr(sites[b0:b1]), int(mode), b1 - b0, V, C.byref(opts), None, _ptr(ws), ws.numel(),
                   _dtype_code(v), _stream()), "nf_rqs_sites")
     return out, logj, sites
+
+
+def multi_rqs_sites(v, params, mask, opts_list, inverse, mode=SITES_LOG):
+    """Per-site values and log-derivatives (or derivatives) of `n_s` splines, one per data channel
+    (MultiRQSplineCoupling_ with propagate_density, couplings_.py:304-329 + nn/_core.py:38-42).
+    v: (B, n_s, V), params: (B, n_s*C, V) -> (value (B, n_s, V), sites (B, n_s, V)).  Inference only."""
+    _require_device(v, params, mask)
+    if v.dtype not in (torch.float32, torch.float64) or params.dtype != v.dtype:
+        raise TypeError(f"per-site derivatives are built for float32 / float64 fields; got {v.dtype} / {params.dtype}")
+    lib = load()
+    B, ns, V = v.shape
+    v, params = v.detach().contiguous(), params.detach().contiguous()
+    Ctot, Vp = params.shape[1], params.shape[2]
+    Cs = Ctot // ns
+    out = torch.empty_like(v)
+    sites = torch.empty(ns, B, V, dtype=v.dtype, device=v.device)
+    logj = torch.empty(B, dtype=v.dtype, device=v.device)
+    ws = _workspace(min(B, MAX_B), V, v.device)
+    fn = lib.nf_rqs_inv_sites if inverse else lib.nf_rqs_fwd_sites
+    esz = v.element_size()
+    st = Strides(ns * V, ns * V, Ctot * Vp)
+    for i, opts in enumerate(opts_list):
+        for b0 in range(0, B, MAX_B):
+            b1 = min(B, b0 + MAX_B)
+            _check(fn(C.c_void_p(v[b0:b1].data_ptr() + i * V * esz),
+                      C.c_void_p(params[b0:b1].data_ptr() + i * Cs * Vp * esz), _ptr(mask), None,
+                      C.c_void_p(out[b0:b1].data_ptr() + i * V * esz), _ptr(logj[b0:b1]), _ptr(sites[i, b0:b1]),
+                      int(mode), b1 - b0, V, C.byref(opts), C.byref(st), _ptr(ws), ws.numel(), _dtype_code(v),
+                      _stream()), "nf_rqs_sites (multi)")
+    return out, sites.movedim(0, 1)
+
+
+def spline_eval(v, kx, ky, kd, K, shared, inverse, grad):
+    """nf_spline_eval: a spline given by explicit knots at every site.  v: (B, V); each knot tensor (K, B*V) planes... laid
+    out (K, V) per batch row when B == 1, or a shared (K,) vector (`shared` = three flags).  Returns (value, derivative|None)."""
+    _require_device(v, kx, ky, kd)
+    B, V = v.shape
+    if B != 1 and not all(shared):
+        raise NotImplementedError("per-site explicit knots are addressed as one (K, V) block: pass B == 1")
+    out = torch.empty_like(v)
+    der = torch.empty_like(v) if grad else None
+    _check(load().nf_spline_eval(_ptr(v), _ptr(kx), _ptr(ky), _ptr(kd), _ptr(out), _ptr(der), B, V, int(K),
+                                 int(shared[0]), int(shared[1]), int(shared[2]), int(bool(inverse)), _dtype_code(v),
+                                 _stream()), "nf_spline_eval")
+    return out, der
 
 
 def rqs_knots(params, opts):
@@ -702,19 +749,23 @@ def invalidate_weight_checks():
 def _weights_fit_fp16(w):
     """finite and inside the fp16 range (the split-fp16 kernel's precondition on the weights); cached per
     parameter version so that the device->host sync happens once per optimiser step, not per launch.
+    An entry belongs to one live tensor OBJECT (the parameter a view like Conv4d.weight is based on), held by weak
+    reference: when that tensor dies its entry goes with it, so a new tensor that reuses the freed address never inherits
+    a verdict, and temporaries (a flipped / transposed copy made for one call) are checked every time.
     In-place ops under no_grad (optimizers, `p.copy_`) bump the version; writes through `p.data` do NOT -- after
     those call `invalidate_weight_checks()` (ModelDeviceHandler.broadcast_parameters does).  Under stream capture
     (GraphedFlow) the check cannot run: only an already cached verdict is accepted, so GraphedFlow validates the
     weights eagerly before it captures and must be re-captured after the weights change."""
-    key = (w.data_ptr(), w._version, tuple(w.shape))
-    ok = _UNIT_OK.get(key)
-    if ok is None:
-        if torch.cuda.is_current_stream_capturing():
-            return False        # cannot synchronise here; the fp32 kernels are always valid
-        if len(_UNIT_OK) > 256:
-            _UNIT_OK.clear()
-        ok = bool(torch.isfinite(w.detach()).all()) and float(w.detach().abs().max()) * SPLIT16_WEIGHT_SCALE < 3.0e4
-        _UNIT_OK[key] = ok
+    base = w._base if w._base is not None else w
+    key = id(base)
+    state = (w._version, w.data_ptr(), tuple(w.shape))
+    hit = _UNIT_OK.get(key)
+    if hit is not None and hit[0]() is base and hit[1] == state:
+        return hit[2]
+    if torch.cuda.is_current_stream_capturing():
+        return False            # cannot synchronise here; the fp32 kernels are always valid
+    ok = bool(torch.isfinite(w.detach()).all()) and float(w.detach().abs().max()) * SPLIT16_WEIGHT_SCALE < 3.0e4
+    _UNIT_OK[key] = (weakref.ref(base, lambda _, k=key: _UNIT_OK.pop(k, None)), state, ok)
     return ok
 
 

@@ -313,7 +313,10 @@ extern "C" int nf_normal_sample(void *x, void *logr, const void *loc, const void
   NF_REQUIRE(x && logr && B >= 0 && B <= 65535 && V >= 0, "nf_normal_sample: bad arguments");
   SampleArgs A{};
   A.x = x; A.loc = loc; A.scale = scale; A.V = V;
-  A.k0 = uint32_t(seed); A.k1 = uint32_t(seed >> 32); A.o0 = uint32_t(offset); A.o1 = uint32_t(offset >> 32);
+  // key = torch's seed with a fixed constant folded into its high word: torch's own Philox kernels key on the bare seed
+  // with the counter words transposed ((offset, subsequence) against this kernel's (group, offset)), so without the
+  // constant one of their threads could replay the raw words of one of this kernel's groups (same 128-bit space)
+  A.k0 = uint32_t(seed); A.k1 = uint32_t(seed >> 32) ^ NF_PHILOX_KEY_DOMAIN; A.o0 = uint32_t(offset); A.o1 = uint32_t(offset >> 32);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == NF_F32) return run_sample<float>(A, logr, B, workspace, workspace_bytes, s);
   if (dtype == NF_F64) return run_sample<double>(A, logr, B, workspace, workspace_bytes, s);

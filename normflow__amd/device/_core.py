@@ -43,8 +43,19 @@ class ModelDeviceHandler:
             torch.cuda.set_device(device)
         self._model.prior.to(device=device)
         self._model.net_.to(device=device)
+        if device.type == 'cpu':
+            self._unshare_cpu_storage()
         self.nranks, self.rank = nranks, rank
         self.broadcast_parameters()
+
+    def _unshare_cpu_storage(self):
+        """torch.multiprocessing hands CPU tensors to spawned children through SHARED memory: without this every rank of a
+        CPU (gloo) run would step the same parameter storage concurrently.  On a GPU `.to(device)` already made the
+        rank's own copy.  Each rank takes a private copy of the parameters and buffers here."""
+        with torch.no_grad():
+            for t in list(self._model.net_.parameters()) + list(self._model.net_.buffers()):
+                if t.is_shared():
+                    t.data = t.detach().clone()
 
     def broadcast_parameters(self, src=0):
         """Every rank takes rank `src`'s parameters.  The copy goes through the parameter itself (under no_grad), not

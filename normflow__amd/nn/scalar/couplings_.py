@@ -9,8 +9,6 @@ ONE fused kernel launch (+ a tiny reduction epilogue) through `normflow__amd._hi
 """
 from abc import ABC, abstractmethod
 
-import os
-
 import torch
 
 from .._core import Module_
@@ -20,6 +18,20 @@ from ...lib.spline import RQSpline
 # Largest raw-logit tensor (bytes) an atom materialises at once; bigger batches are
 # cut into slabs (32^4, m=16: one sample's logits are 193 MB in fp32).
 PARAM_SLAB_BYTES = 6 << 30
+# Largest hidden-activation tensor (fp32-equivalent bytes) a fused atom materialises at once (256 samples of 32^4).
+HIDDEN_SLAB_BYTES = 8 << 30
+
+
+def set_slab_bytes(params=None, hidden=None):
+    """Planner knobs of this module (the product reads no environment variable): byte budgets of the logit slab of an
+    unfused atom and of the hidden-activation slab of a fused one.  Returns the previous (params, hidden)."""
+    global PARAM_SLAB_BYTES, HIDDEN_SLAB_BYTES
+    old = (PARAM_SLAB_BYTES, HIDDEN_SLAB_BYTES)
+    if params is not None:
+        PARAM_SLAB_BYTES = int(params)
+    if hidden is not None:
+        HIDDEN_SLAB_BYTES = int(hidden)
+    return old
 
 
 def _activity_bytes(mask, channel, lattice_shape, device):
@@ -103,18 +115,35 @@ class Coupling_(Module_, ABC):
             raise NotImplementedError("propagate_density=True (per-site densities) is not provided by "
                                       "this coupling's kernels, which reduce log|J| per sample")
 
-    def _affine_density_atom(self, inverse, x_active, x_frozen, parity, net, log0):
-        """propagate_density (nn/_core.py:19,38-42) for the affine / shift layers: log0 + the log-derivative of every site
-        (nf_affine_sites), nothing summed.  Inference only."""
+    def _no_grad_only(self, x_active, x_frozen, net):
         if torch.is_grad_enabled() and (x_active.requires_grad or x_frozen.requires_grad
                                         or any(p.requires_grad for p in net.parameters())):
             raise NotImplementedError("propagate_density=True is an inference path here (per-site densities have no VJP "
                                       "kernel); wrap the call in torch.no_grad()")
+
+    def _density_slabs(self, x_active, x_frozen, net, n_out_hint, one_slab):
+        """Per-site densities, slab by slab like `_run_atom` (the logits of a whole batch need not fit in memory):
+        `one_slab(x_active[b0:b1], x_frozen[b0:b1]) -> (value, per-site log-derivative)`, written into preallocated rows."""
         B = x_active.shape[0]
+        n_out = getattr(net, 'conv_kwargs', {}).get('out_channels', n_out_hint)
+        per_sample = n_out * x_active[0].numel() * x_active.element_size()
+        val, sites = torch.empty_like(x_active), torch.empty_like(x_active)
+        for b0, b1 in self._slabs(B, per_sample):
+            val[b0:b1], sites[b0:b1] = one_slab(x_active[b0:b1], x_frozen[b0:b1])
+        return val, sites
+
+    def _affine_density_atom(self, inverse, x_active, x_frozen, parity, net, log0):
+        """propagate_density (nn/_core.py:19,38-42) for the affine layer: log0 + the log-derivative of every site
+        (nf_affine_sites), nothing summed.  Inference only."""
+        self._no_grad_only(x_active, x_frozen, net)
         act = self._activity(parity, x_active.shape[1:], x_active.device)
-        params, layout = self._params(net, x_frozen, None)
-        val, _, sites = _hip.affine_sites(x_active.reshape(B, -1), params, act, None, layout, inverse)
-        return val.reshape(x_active.shape), log0 + sites.reshape(x_active.shape)
+
+        def one_slab(xa, xf):
+            params, layout = self._params(net, xf, None)
+            val, _, sites = _hip.affine_sites(xa.reshape(xa.shape[0], -1), params, act, None, layout, inverse)
+            return val.reshape(xa.shape), sites.reshape(xa.shape)
+        val, sites = self._density_slabs(x_active, x_frozen, net, 2, one_slab)
+        return val, log0 + sites
 
     def _params(self, net, x_frozen, parity=None):
         """Run the parameter net; return raw logits as (B, C, V) [or (B, C, V/2)] and the
@@ -138,9 +167,10 @@ class Coupling_(Module_, ABC):
         step = max(1, min(B, (budget or PARAM_SLAB_BYTES) // max(1, per_sample_bytes)))
         return [(b0, min(B, b0 + step)) for b0 in range(0, B, step)]
 
-    def _run_atom(self, kernel, x_active, x_frozen, parity, net, log0, n_out_hint):
+    def _run_atom(self, kernel, x_active, x_frozen, parity, net, log0, n_out_hint, density_ok=False):
         """Common driver: slab the batch, produce logits, launch `kernel(v, params, l0, act, layout)`."""
-        self._check_density()
+        if not density_ok:
+            self._check_density()
         B = x_active.shape[0]
         lattice = x_active.shape[1:]
         act = self._activity(parity, lattice, x_active.device)
@@ -162,9 +192,11 @@ class ShiftCoupling_(Coupling_):
     """y = purify(x + t) (couplings_.py:107-116); log|J| unchanged."""
 
     def _atom(self, inverse, *, x_active, x_frozen, parity, net, log0=0):
-        if self.propagate_density:
-            return self._affine_density_atom(inverse, x_active, x_frozen, parity, net, log0)
         k = lambda v, p, l0, act, layout: _hip.AffineCouplingFn.apply(v, p, l0, act, layout, inverse)
+        if self.propagate_density:
+            # a shift has unit Jacobian: the reference hands log0 back untouched, whatever its shape (couplings_.py:110-116)
+            val, _ = self._run_atom(k, x_active, x_frozen, parity, net, 0, 1, density_ok=True)
+            return val, log0
         val, lj = self._run_atom(k, x_active, x_frozen, parity, net, log0, 1)
         return val, (lj if torch.is_tensor(log0) or log0 != 0 else log0)
 
@@ -177,8 +209,6 @@ class ShiftCoupling_(Coupling_):
 
 class AffineCoupling_(Coupling_):
     """y = t + x e^{-|s|}, log|J| = -sum|s| over the active sites (couplings_.py:120-139)."""
-
-    HIDDEN_SLAB_BYTES = int(float(os.environ.get("NF_HIDDEN_SLAB_GIB", "8")) * (1 << 30))
 
     def _fused_atom(self, inverse, x_active, x_frozen, parity, net, log0):
         """Inference fast path on the split-fp16 chain: first layer -> pair tensor, hidden layers, and the net's last layer
@@ -201,7 +231,7 @@ class AffineCoupling_(Coupling_):
         val = torch.empty_like(v)
         lj = torch.empty(B, dtype=torch.float32, device=v.device)
         lattice = tuple(x_frozen.shape[1:])
-        for b0, b1 in self._slabs(B, hidden * v.shape[1] * 4, self.HIDDEN_SLAB_BYTES):
+        for b0, b1 in self._slabs(B, hidden * v.shape[1] * 4, HIDDEN_SLAB_BYTES):
             xf = x_frozen[b0:b1]
             got = net.hidden_and_last(self.preprocess_fz(xf.float() if xf.dtype == torch.float16 else xf), last_kind='affine')
             if got is None:
@@ -267,9 +297,6 @@ class RQSplineCoupling_(Coupling_):
                 raise Exception(f"fixed knots have {k.numel()} entries but the net output implies m={m}")
         return _hip.make_rqs_opts(m, self.xlim, self.ylim, self.extrap, layout, kx, ky)
 
-    # Largest hidden-activation tensor (bytes) the fused path materialises at once.
-    HIDDEN_SLAB_BYTES = int(float(os.environ.get("NF_HIDDEN_SLAB_GIB", "8")) * (1 << 30))     # fp32-equivalent bytes of hidden activations per slab
-
     def _fused_atom(self, inverse, x_active, x_frozen, parity, net, log0):
         """Inference fast path: ConvAct's last layer and the spline in ONE kernel (nf_conv_rqs);
         the logits never reach HBM.  Returns None when it does not apply."""
@@ -292,7 +319,7 @@ class RQSplineCoupling_(Coupling_):
         v = v.contiguous()
         val = torch.empty_like(v)               # the slabs write their rows in place: no concatenation
         lj = torch.empty(B, dtype=torch.float32 if v.dtype == torch.float16 else v.dtype, device=v.device)
-        for b0, b1 in self._slabs(B, hidden * v.shape[1] * 4, self.HIDDEN_SLAB_BYTES):
+        for b0, b1 in self._slabs(B, hidden * v.shape[1] * 4, HIDDEN_SLAB_BYTES):
             xf = x_frozen[b0:b1]
             got = net.hidden_and_last(self.preprocess_fz(xf.float() if xf.dtype == torch.float16 else xf))
             if got is None:
@@ -314,7 +341,7 @@ class RQSplineCoupling_(Coupling_):
         """(spline, f(x_active), log g) of one layer with nothing summed (couplings_.py:202-209); the last two are zero off
         the active sublattice.  Inspection only: no autograd."""
         with torch.no_grad():
-            out = net(self.preprocess_fz(x_frozen))
+            out = net(self.preprocess_fz(x_frozen))        # the spline object holds the whole batch's logits: no slabs here
             spline = self.make_spline(out)
             act = self._activity(parity, x_active.shape[1:], x_active.device)
             fx, logg = spline._map(x_active, False, True, True, activity=act, log=True)
@@ -322,13 +349,13 @@ class RQSplineCoupling_(Coupling_):
 
     def _density_atom(self, inverse, x_active, x_frozen, parity, net, log0):
         """propagate_density (nn/_core.py:19,38-42): log0 + the log-derivative of every site, nothing summed."""
-        if torch.is_grad_enabled() and (x_active.requires_grad or x_frozen.requires_grad
-                                        or any(p.requires_grad for p in net.parameters())):
-            raise NotImplementedError("propagate_density=True is an inference path here (per-site densities have no VJP "
-                                      "kernel); wrap the call in torch.no_grad()")
+        self._no_grad_only(x_active, x_frozen, net)
         act = self._activity(parity, x_active.shape[1:], x_active.device)
-        spline = self.make_spline(net(self.preprocess_fz(x_frozen)))
-        val, logg = spline._map(x_active, inverse, True, True, activity=act, log=True)
+
+        def one_slab(xa, xf):
+            spline = self.make_spline(net(self.preprocess_fz(xf)))
+            return spline._map(xa, inverse, True, True, activity=act, log=True)
+        val, logg = self._density_slabs(x_active, x_frozen, net, 46, one_slab)
         return val, log0 + logg
 
     def _atom(self, inverse, *, x_active, x_frozen, parity, net, log0=0):
@@ -372,25 +399,56 @@ class MultiRQSplineCoupling_(Coupling_):
     def preprocess_fz(self, x):
         return x
 
+    def _spline_opts(self, Cs, like):
+        """One option block per spline; knots_len from the channels each spline gets (couplings_.py:383-401): 3m-2 free,
+        2m-1 with knots_x[i] or knots_y[i] fixed, m with both."""
+        opts = []
+        for i in range(self.num_splines):
+            fix = lambda k: None if k is None else torch.as_tensor(k).detach().to(
+                device=like.device, dtype=like.dtype).contiguous()
+            kx, ky = fix(self.knots_x[i]), fix(self.knots_y[i])
+            for k in (kx, ky):
+                if k is not None and k.dim() != 1:
+                    raise NotImplementedError("only 1-D fixed knots_x / knots_y are supported")
+            n_fixed = (kx is not None) + (ky is not None)
+            div = 3 - n_fixed
+            if (Cs + 2 - n_fixed) % div:
+                raise Exception(f"spline {i} gets {Cs} channels; {div}m-{2 - n_fixed} are needed for m knots")
+            m = (Cs + 2 - n_fixed) // div
+            for k in (kx, ky):
+                if k is not None and k.numel() != m:
+                    raise Exception(f"fixed knots of spline {i} have {k.numel()} entries but its channels imply m={m}")
+            opts.append(_hip.make_rqs_opts(m, self.xlims[i], self.ylims[i], self.extraps[i], _hip.LAYOUT_FULL, kx, ky))
+        return opts
+
     def _atom(self, inverse, *, x_active, x_frozen, parity, net, log0=0):
-        self._check_density()
-        if any(k is not None for k in list(self.knots_x) + list(self.knots_y)):
-            raise NotImplementedError("fixed knots_x / knots_y are not supported by the HIP kernels yet")
-        if self.channels_axis != 1:
-            raise NotImplementedError("MultiRQSplineCoupling_ kernels need channels_axis=1")
-        B, ns = x_active.shape[0], self.num_splines
+        ns = self.num_splines
+        out = net(self.preprocess_fz(x_frozen))
+        ax = self.channels_axis
+        on_axis1 = ax in (1, 1 - out.dim())
+        if not on_axis1:                       # the kernels address channels on axis 1
+            out, x_active = out.movedim(ax, 1), x_active.movedim(ax, 1)
+        B = x_active.shape[0]
+        if x_active.shape[1] != ns:
+            raise Exception(f"x has {x_active.shape[1]} channels on axis {ax} for {ns} splines")
         lattice = x_active.shape[2:]
         act = self._activity(parity, lattice, x_active.device)
-        out = net(self.preprocess_fz(x_frozen))
         params = out.reshape(B, out.shape[1], -1)
         Cs = params.shape[1] // ns
-        if Cs * ns != params.shape[1] or (Cs + 2) % 3:
-            raise Exception(f"net output has {params.shape[1]} channels; need num_splines*(3m-2)")
-        opts = [_hip.make_rqs_opts((Cs + 2) // 3, self.xlims[i], self.ylims[i], self.extraps[i],
-                                   _hip.LAYOUT_FULL) for i in range(ns)]
+        if Cs * ns != params.shape[1]:
+            raise Exception(f"net output has {params.shape[1]} channels; need num_splines equal parts")
+        opts = self._spline_opts(Cs, x_active)
         v = x_active.reshape(B, ns, -1)
+        back = (lambda t: t) if on_axis1 else (lambda t: t.movedim(1, ax))
+        if self.propagate_density:
+            # log0 + the log-derivative of every site of every spline, nothing summed (nn/_core.py:38-42)
+            if torch.is_grad_enabled() and (v.requires_grad or params.requires_grad):
+                raise NotImplementedError("propagate_density=True is an inference path here (per-site densities have no "
+                                          "VJP kernel); wrap the call in torch.no_grad()")
+            val, sites = _hip.multi_rqs_sites(v, params, act, opts, inverse)
+            return back(val.reshape(x_active.shape)), log0 + back(sites.reshape(x_active.shape))
         val, lj = _hip.MultiRQSCouplingFn.apply(v, params, _hip._log0_tensor(log0, v, B), act, opts, inverse)
-        return val.reshape(x_active.shape), lj
+        return back(val.reshape(x_active.shape)), lj
 
     def atomic_forward(self, **kw):
         return self._atom(False, **kw)

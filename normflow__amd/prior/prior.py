@@ -2,10 +2,16 @@
 
 API kept from the reference (src/prior/prior.py): `sample(B)`, `sample_(B) -> (x, log r)`,
 `log_prob(x)`, `.to(...)`, `.shape`, `.nvar`, `.parameters`, `.dist`.  The implementation is this
-package's own: a prior is described by two tensors (location / scale, or low / high); samples
-are drawn with the same torch generator calls `torch.distributions` makes (so a seed produces
-the reference's stream), and the normal log-density of device tensors is ONE fused HIP pass
-(`nf_normal_logprob`) instead of log_prob + sum.
+package's own: a prior is described by two tensors (location / scale, or low / high).  On a HIP
+device `NormalPrior.sample` and `sample_` BOTH draw through the fused Philox kernel
+(`nf_normal_sample`: one launch emits x and log r), keyed by torch's CUDA generator: after the
+same `torch.manual_seed`, `sample(B)` and `sample_(B)[0]` are the same configurations, as they
+are in the reference (both go through `dist.sample`, prior.py:22-28).  The random STREAM is this
+kernel's, not torch's (the reference's stream is whatever torch's sampler gives and is not part
+of its contract); `NormalPrior(..., torch_rng=True)` keeps torch's sampler -- the reference's
+stream on a given seed -- for both methods.  Elsewhere (CPU tensors, UniformPrior) samples are
+drawn with the same torch generator calls `torch.distributions` makes.  The normal log-density
+of device tensors is ONE fused HIP pass (`nf_normal_logprob`) instead of log_prob + sum.
 """
 import math
 
@@ -79,15 +85,27 @@ class NormalPrior(Prior):
         super().__init__(loc, scale, seed)
         self.torch_rng = torch_rng
 
+    def _kernel_draws(self, batch_size):
+        loc = self.loc
+        return (not self.torch_rng and loc.is_cuda and loc.dtype in (torch.float32, torch.float64) and batch_size >= 1)
+
+    def _kernel_sample(self, batch_size):
+        unit = self._unit
+        return _hip.normal_sample(None if unit else self.loc.reshape(-1), None if unit else self.scale.reshape(-1),
+                                  batch_size, self.shape, self.loc.dtype, self.loc.device)
+
+    def sample(self, batch_size=1):
+        """x alone (prior.py:22-24), from the same generator and kernel as `sample_`: one seed, one stream."""
+        if self._kernel_draws(batch_size):
+            return self._kernel_sample(batch_size)[0]
+        return super().sample(batch_size)
+
     def sample_(self, batch_size=1):
         """(x, log r) (prior.py:26-29): on a HIP device ONE kernel (nf_normal_sample) draws the field and accumulates its
         log-density from the normals still in registers."""
-        loc = self.loc
-        if (not self.torch_rng and not self.propagate_density and loc.is_cuda
-                and loc.dtype in (torch.float32, torch.float64) and batch_size >= 1):
-            unit = self._unit
-            return _hip.normal_sample(None if unit else loc.reshape(-1), None if unit else self.scale.reshape(-1),
-                                      batch_size, self.shape, loc.dtype, loc.device)
+        if self._kernel_draws(batch_size):
+            x, logr = self._kernel_sample(batch_size)
+            return x, (self.log_prob(x) if self.propagate_density else logr)
         return super().sample_(batch_size)
 
     loc = property(lambda self: self._p[0])

@@ -493,6 +493,7 @@ def kl_loss(logq, logp):
 # that the kernel's draws can be checked number by number.
 PHILOX_M0, PHILOX_M1 = 0xD2511F53, 0xCD9E8D57
 PHILOX_W0, PHILOX_W1 = 0x9E3779B9, 0xBB67AE85
+PHILOX_KEY_DOMAIN = 0x6E66686B     # NF_PHILOX_KEY_DOMAIN of include/normflow_hip.h: XORed into the high key word
 
 
 def philox4x32_10(counter, key):
@@ -516,7 +517,8 @@ def philox4x32_10(counter, key):
 def normal_prior_sample(seed, offset, B, V, loc=None, scale=None, dtype=torch.float32):
     """(x (B, V), logr (B)) exactly as nf_normal_sample lays its draws out (include/normflow_hip.h):
     group q = element index // 4 of sample b (float32: 4 normals per Philox call) or // 2 (float64: 2 per call);
-    counter = (lo32(g), hi32(g), lo32(offset), hi32(offset)) with g = b * ngroups + q, key = (lo32(seed), hi32(seed));
+    counter = (lo32(g), hi32(g), lo32(offset), hi32(offset)) with g = b * ngroups + q, key = (lo32(seed), hi32(seed) ^
+    PHILOX_KEY_DOMAIN);
     Box-Muller: float32 u1 = (r + 1) 2^-32, u2 = r' 2^-32 from (r0, r1) -> (z0, z1) = rho (cos, sin)(2 pi u2) and (r2, r3) ->
     (z2, z3); float64 u1 = ((r0 << 21 ^ r1 >> 11) + 1) 2^-53, u2 likewise from (r2, r3) without the + 1.
     x = loc + scale z;  logr = sum_x [-z^2/2 - log scale - log sqrt(2 pi)]."""
@@ -526,7 +528,8 @@ def normal_prior_sample(seed, offset, B, V, loc=None, scale=None, dtype=torch.fl
     g = (np.arange(B, dtype=np.uint64)[:, None] * np.uint64(ngroups) + np.arange(ngroups, dtype=np.uint64)[None, :])
     ctr = np.stack([(g & np.uint64(0xFFFFFFFF)), (g >> np.uint64(32)),
                     np.full_like(g, offset & 0xFFFFFFFF), np.full_like(g, (offset >> 32) & 0xFFFFFFFF)], axis=-1).astype(np.uint32)
-    key = np.broadcast_to(np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32), g.shape + (2,))
+    key = np.broadcast_to(np.array([seed & 0xFFFFFFFF, ((seed >> 32) & 0xFFFFFFFF) ^ PHILOX_KEY_DOMAIN], dtype=np.uint32),
+                          g.shape + (2,))
     r = philox4x32_10(ctr, key).astype(np.float64)
     if dtype == torch.float32:
         def bm(ra, rb):

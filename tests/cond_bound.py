@@ -40,11 +40,18 @@ def _segment_eval(x, x0, x1, y0, y1, d0, d1):
     return val, torch.log(g), (s, th, t1, den)
 
 
-def rqs_forward_bound(x, out, *, xlim, ylim, extrap=None, knots_x=None, knots_y=None, eps=EPS32):
+def rqs_forward_bound(x, out, **kw):
     """x: (N,) float64 inputs of N active sites, out: (N, C) float64 raw logits.  Returns float64 numpy arrays
     (y, logg, bound_y, bound_logg) of the float64 oracle's per-site values and the per-site float32 bounds."""
-    x = torch.as_tensor(np.asarray(x), dtype=torch.float64)
-    out = torch.as_tensor(np.asarray(out), dtype=torch.float64)
+    with torch.device("cpu"):          # the package makes the GPU torch's default device; this is CPU arithmetic
+        return _forward_bound(x, out, **kw)
+
+
+def _forward_bound(x, out, *, xlim, ylim, extrap=None, knots_x=None, knots_y=None, eps=EPS32):
+    x = torch.as_tensor(np.asarray(x), dtype=torch.float64, device="cpu")
+    out = torch.as_tensor(np.asarray(out), dtype=torch.float64, device="cpu")
+    knots_x = knots_x.cpu() if torch.is_tensor(knots_x) else knots_x
+    knots_y = knots_y.cpu() if torch.is_tensor(knots_y) else knots_y
     N = x.shape[0]
     o = out.t().unsqueeze(0)                                   # (1, C, N): channel axis 1, as the oracle expects
     kx, ky, kd = O.knots_from_logits(o, xlim, ylim, knots_x, knots_y)
@@ -111,11 +118,18 @@ def _segment_invert(w, x0, x1, y0, y1, d0, d1, r):
     return x0 + (x1 - x0) * th, -torch.log(g), (s, t1, den, amp)
 
 
-def rqs_inverse_bound(w, out, *, xlim, ylim, extrap=None, knots_x=None, knots_y=None, eps=EPS32):
+def rqs_inverse_bound(w, out, **kw):
     """The same statement for the inverse map x = f^-1(w), -log g: w (N,) float64, out (N, C).  Returns
     (x, -logg, bound_x, bound_logg)."""
-    w = torch.as_tensor(np.asarray(w), dtype=torch.float64)
-    out = torch.as_tensor(np.asarray(out), dtype=torch.float64)
+    with torch.device("cpu"):
+        return _inverse_bound(w, out, **kw)
+
+
+def _inverse_bound(w, out, *, xlim, ylim, extrap=None, knots_x=None, knots_y=None, eps=EPS32):
+    w = torch.as_tensor(np.asarray(w), dtype=torch.float64, device="cpu")
+    out = torch.as_tensor(np.asarray(out), dtype=torch.float64, device="cpu")
+    knots_x = knots_x.cpu() if torch.is_tensor(knots_x) else knots_x
+    knots_y = knots_y.cpu() if torch.is_tensor(knots_y) else knots_y
     N = w.shape[0]
     o = out.t().unsqueeze(0)
     kx, ky, kd = O.knots_from_logits(o, xlim, ylim, knots_x, knots_y)

@@ -319,3 +319,52 @@ def test_conv_weight_layout_planning_and_packers():
             want = float(wf[col, ci, row, j3]) if col < w.shape[0] else 0.0
             assert float(p[row, kq, lane, j3 * nt + t]) == want
         assert float(p[..., k3 * nt:].abs().sum()) == 0.0
+
+
+def test_rqspline_explicit_knots_host_side():
+    """`RQSpline(knots_x=, knots_y=, knots_d=, knots_axis=, extrap=)` (spline.py:39-68): the stored knots after the
+    boundary augmentation (spline.py:458-532), the knots_d=None smoothing (:125-152), the 'anti-periodic' alias and the
+    reference's shape errors -- host logic, no kernel call (evaluation needs the GPU: tests/test_gpu_parity.py)."""
+    from normflow__amd.lib.spline import RQSpline
+    torch.manual_seed(3)
+    with torch.device("cpu"):
+        out = 0.7 * torch.randn(2, 13, 4, 3, dtype=torch.float64)
+        kx, ky, kd = O.knots_from_logits(out, (-1.0, 2.0), (0.0, 3.0))
+        for extrap in ({}, {'left': 'linear', 'right': 'linear'}, {'left': 'anti', 'right': 'linear'}, {'right': 'anti-periodic'}):
+            want = O.augment_knots(kx, ky, kd, axis=1, **extrap)
+            sp = RQSpline(knots_x=kx, knots_y=ky, knots_d=kd, knots_axis=1, extrap=extrap)
+            sl = RQSpline(knots_x=kx.movedim(1, -1), knots_y=ky.movedim(1, -1), knots_d=kd.movedim(1, -1), extrap=extrap)
+            assert sp.knots_len == want[0].shape[1] == sl.knots_len and sp.segm_len == sp.knots_len - 1
+            assert tuple(sp.knots_shape) == tuple(want[0].shape)
+            for got, got_last, w in zip((sp.knots_x, sp.knots_y, sp.knots_d), (sl.knots_x, sl.knots_y, sl.knots_d), want):
+                assert torch.equal(got, w) and torch.equal(got_last.movedim(-1, 1), w)
+        # 1-D knots_x against N-D knots_y with a boundary rule: every tensor gets the full shape first
+        kx1 = torch.linspace(-1.0, 2.0, 5, dtype=torch.float64)
+        sp = RQSpline(knots_x=kx1, knots_y=ky, knots_d=kd, knots_axis=1, extrap={'left': 'linear'})
+        want = O.augment_knots(kx1, ky, kd, axis=1, left='linear')
+        assert torch.equal(sp.knots_x, want[0]) and torch.equal(sp.knots_y, want[1])
+        # knots_d = None
+        sp = RQSpline(knots_x=kx1, knots_y=ky[0, :, 0, 0].contiguous(), knots_d=None)
+        y1 = ky[0, :, 0, 0]
+        s = (y1[1:] - y1[:-1]) / (kx1[1:] - kx1[:-1])
+        assert torch.allclose(sp.knots_d, torch.cat((s[:1], 0.5 * (s[1:] + s[:-1]), s[-1:])), rtol=0, atol=1e-15)
+        with pytest.raises(Exception, match="same shape"):
+            RQSpline(knots_x=kx, knots_y=ky[:, :, :2], knots_d=kd)
+        with pytest.raises(Exception, match="not supported"):
+            RQSpline(knots_x=kx, knots_y=ky, knots_d=kd, knots_axis=1, extrap={'left': 'periodic'})
+        # and without a device there is no evaluation: the product has no CPU path
+        with pytest.raises(_hip.NormflowHipError):
+            RQSpline(knots_x=kx, knots_y=ky, knots_d=kd, knots_axis=1)(torch.zeros(2, 1, 4, 3, dtype=torch.float64))
+
+
+def test_coupling_slab_budgets_are_module_settings():
+    """The planner knobs are module attributes with a setter -- the product reads no environment variable for them."""
+    from normflow__amd.nn.scalar import couplings_
+    old = couplings_.set_slab_bytes(hidden=1 << 20)
+    try:
+        assert couplings_.HIDDEN_SLAB_BYTES == 1 << 20 and couplings_.PARAM_SLAB_BYTES == old[0]
+    finally:
+        couplings_.set_slab_bytes(*old)
+    assert (couplings_.PARAM_SLAB_BYTES, couplings_.HIDDEN_SLAB_BYTES) == old
+    src = open(couplings_.__file__).read()
+    assert "os.environ" not in src and "getenv" not in src

@@ -24,6 +24,11 @@ def _opts(z, tag, dtype=torch.float64):
 
 def _oracle32_sites(z, tag, inverse):
     """per-site (value, log-derivative) of the oracle's float32 evaluation: (B, S, n) arrays."""
+    with torch.device("cpu"):
+        return _oracle32_sites_cpu(z, tag, inverse)
+
+
+def _oracle32_sites_cpu(z, tag, inverse):
     kind = tag.split("/")[0]
     opts = _opts(z, tag, torch.float32)
     b = CB.case_bounds(z, tag, _opts(z, tag), inverse)       # only for the index bookkeeping

@@ -116,3 +116,35 @@ def test_spawnprocesses_reports_a_failed_child():
     with pytest.warns(UserWarning, match="master_port"):
         with pytest.raises(ProcessRaisedException, match="worker failed on purpose"):
             model.device_handler.spawnprocesses(_failing_worker, 2, _free_port(), [1, 2])
+
+
+def _four_rank_worker(model, out_dir):
+    """Three optimizer steps by hand on 4 ranks: distinct shards, ONE flat all-reduce per step, and the parameters of all
+    ranks stay the same bits after every step (what the 8-GPU run of Model.fit relies on, src/device/_core.py:51-95)."""
+    dh = model.device_handler
+    assert dh.nranks == 4
+    params = list(model.net_.parameters())
+    opt = torch.optim.AdamW(params, lr=0.05, weight_decay=0.0)
+    states = []
+    for step in range(3):
+        opt.zero_grad(set_to_none=True)
+        x, logr = model.prior.sample_(32)
+        y, logJ = model.net_(x)
+        model.fit.calc_kl_mean(logr - logJ, -model.action(y)).backward()
+        dh.all_reduce_gradients()
+        opt.step()
+        flat = torch.cat([p.detach().reshape(-1) for p in params])
+        every = dh.all_gather_into_tensor(flat.unsqueeze(0))
+        assert all(torch.equal(every[0], every[r]) for r in range(1, 4)), f"ranks diverged at step {step}"
+        states.append(flat.clone())
+    assert not torch.equal(states[0], states[2])          # the steps did move the parameters
+    with open(os.path.join(out_dir, f"rank{dh.rank}.json"), "w") as f:
+        json.dump({"params": states[-1].tolist()}, f)
+
+
+def test_spawnprocesses_four_ranks_three_steps_bit_identical():
+    model = make_cpu_model(seed=9)
+    with tempfile.TemporaryDirectory() as tmp:
+        model.device_handler.spawnprocesses(_four_rank_worker, 4, _free_port(), [11, 22, 33, 44], tmp)
+        got = [json.load(open(os.path.join(tmp, f"rank{r}.json")))["params"] for r in range(4)]
+    assert got[0] == got[1] == got[2] == got[3]
