@@ -774,7 +774,7 @@ def conv_supported(x, weight):
             and 1 <= x.dim() - 2 <= 4)
 
 
-def _conv_launch(x, weight, bias, act, compact, parity):
+def _conv_launch(x, weight, bias, act, compact, parity, weight_src=None):
     """One launch sequence of nf_conv_fwd for a (cout, cin, *k) weight tensor; packs the weights in
     the fragment layout the library will use (two-site column packing for cout <= 8)."""
     lib = load()
@@ -785,7 +785,8 @@ def _conv_launch(x, weight, bias, act, compact, parity):
     lat4 = (C.c_int32 * 4)(*([1] * (4 - d) + lat))
     k4 = (C.c_int32 * 4)(*([1] * (4 - d) + ksize))
     split16 = compact == 2                 # NF_OUT_SPLIT16: the fp16 (hi, lo) pair tensor, (B, V, 16) halfs
-    if (split16 and cin == 1 and cout == 8 and d == 4 and x.dtype == torch.float32 and _weights_fit_fp16(weight)
+    if (split16 and cin == 1 and cout == 8 and d == 4 and x.dtype == torch.float32
+            and _weights_fit_fp16(weight if weight_src is None else weight_src)     # (the caller's tensor: its verdict is cached)
             and lib.nf_conv_first_split16_supported(lat4, k4, cout, act)):
         return conv_first_split16(x, weight, bias, act)
     if split16 and not (lib.nf_conv_two_site(cout, 0, lat[-1], ksize[-1]) and cout == 8 and x.dtype == torch.float32):
@@ -987,7 +988,7 @@ class ConvFn(torch.autograd.Function):
         elif compact and act == 0 and x.dim() == 6 and weight.shape[0] == 46:
             out = conv_last_logits_split16(x, weight, bias, parity)     # ... and its 8 -> 46 layer at the active sites
         if out is None:
-            out = _conv_launch(x, weight.detach(), bias, act, compact, parity)
+            out = _conv_launch(x, weight.detach(), bias, act, compact, parity, weight_src=weight)
         ctx.save_for_backward(x, weight, out if act else None)
         ctx.act, ctx.compact, ctx.parity, ctx.has_bias = act, compact, parity, bias is not None
         return out
@@ -1041,7 +1042,7 @@ def conv_layer(x, weight, bias, act=0, compact=False, parity=0):
             return torch.abs(ConvFn.apply(x, weight, bias, 0, compact, parity))
         return ConvFn.apply(x, weight, bias, act, compact, parity)
     x = x.contiguous()
-    return _conv_launch(x, weight.detach(), None if bias is None else bias.detach(), act, compact, parity)
+    return _conv_launch(x, weight.detach(), None if bias is None else bias.detach(), act, compact, parity, weight_src=weight)
 
 
 def conv_affine_split16(h16, weight, bias, x_active, log0, parity, inverse, lattice, out=None):

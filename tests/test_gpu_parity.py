@@ -1822,8 +1822,9 @@ def test_rqspline_from_explicit_knots_vs_oracle(layout, dtype):
             if layout == "shared":
                 fo, go = O.rqs_evaluate(akx.reshape(-1, 1), aky.reshape(-1, 1), akd.reshape(-1, 1), vv.reshape(1, -1), axis=0)
                 fo, go = fo.reshape(vv.shape), go.reshape(vv.shape)
-            else:
-                fo, go = O.rqs_evaluate(O._bcast_like(akx, aky), aky, akd, vv, axis=1)
+            else:               # the oracle evaluates one point per spline: the two points of the knots axis one by one
+                pts = [O.rqs_evaluate(O._bcast_like(akx, aky), aky, akd, vv[:, r:r + 1], axis=1) for r in range(vv.shape[1])]
+                fo, go = torch.cat([p[0] for p in pts], 1), torch.cat([p[1] for p in pts], 1)
         to = lambda t: t.to(DEV, dtype)
         if layout == "nd_last":
             sp = RQSpline(knots_x=to(kx.movedim(1, -1)), knots_y=to(ky.movedim(1, -1)), knots_d=to(kd.movedim(1, -1)),
