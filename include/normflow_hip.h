@@ -344,6 +344,11 @@ int nf_conv_last_path(void);
  *   BASELINE config 5, "fp16 params / fp32 log-det accumulate" -- in the fused path the "params" never exist in memory). */
 enum { NF_CONV_UNIT_INPUT = 1, NF_CONV_SPLIT16_INPUT = 2, NF_CONV_FIELD_F16 = 4 };
 int nf_conv_rqs_supported(int cout, int m);
+/* Planning query for the split-fp16 chain: its fused last layer takes ANY knots_len 2 <= m <= 16 (cout = 3m - 2 <= 46
+ * logit channels: the reference leaves knots_len free, src/nn/scalar/couplings_.py:211-262) on 4-D lattices with even
+ * extents and a fastest axis of 32 + 16 n sites, fed by the pair tensor (NF_CONV_UNIT_INPUT | NF_CONV_SPLIT16_INPUT).
+ * Hidden widths below 8 run the same kernels on weights zero-padded to 8 channels (the host packs them). */
+int nf_conv_rqs_split16_supported(const int32_t *lattice, int cout, int m);
 int nf_conv_rqs(const void *in, const void *wfrag, const void *bias, const void *x_active,
                 const void *log0, void *y, void *logj, int64_t B, const int32_t *lattice,
                 const int32_t *ksize, int cin, int cout, int active_parity,

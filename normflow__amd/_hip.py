@@ -83,6 +83,7 @@ PROTOTYPES = {
     "nf_conv_wgrad_split16_workspace": (_SZ, [_I64, C.POINTER(C.c_int32), _I]),
     "nf_conv_wgrad_split16": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _P, _I, _P, _SZ, _P]),
     "nf_conv_rqs_supported": (_I, [_I, _I]),
+    "nf_conv_rqs_split16_supported": (_I, [C.POINTER(C.c_int32), _I, _I]),
     "nf_conv_last_path": (_I, []),
     "nf_conv_split16_supported": (_I, [_P, _P, _I, _I, _I]),
     "nf_conv_fwd_split16": (_I, [_P, _P, _P, _P, _I64, _P, _I, _P]),

@@ -775,6 +775,16 @@ extern "C" int nf_conv_rqs_supported(int cout, int m) {
   return (m == 4 || m == 8 || m == 16) && cout == 3 * m - 2;
 }
 
+// The split-fp16 fused kernel (nf_conv_h.hip) takes any knots_len 2..16 on its lattices (4-D, even extents, fastest axis
+// 32 + 16 n sites, 3^4 kernel, 8 hidden channels): a host-side planning query, no launch.
+extern "C" int nf_conv_rqs_split16_supported(const int32_t *lattice, int cout, int m) {
+  if (!lattice || m < 2 || m > 16 || cout != 3 * m - 2 || !option(NF_OPT_SPLIT16)) return 0;
+  if (lattice[3] < 32 || (lattice[3] & 15)) return 0;
+  for (int mu = 0; mu < 3; ++mu)
+    if (lattice[mu] < 2 || (lattice[mu] & 1)) return 0;
+  return 1;
+}
+
 extern "C" int nf_conv_rqs(const void *in, const void *wfrag, const void *bias, const void *x_active,
                            const void *log0, void *y, void *logj, int64_t B, const int32_t *lattice,
                            const int32_t *ksize, int cin, int cout, int active_parity,
@@ -782,7 +792,10 @@ extern "C" int nf_conv_rqs(const void *in, const void *wfrag, const void *bias, 
                            int dtype, void *stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   NF_REQUIRE(opts && x_active && y && logj && lattice, "nf_conv_rqs: NULL pointer");
-  NF_REQUIRE(nf_conv_rqs_supported(cout, opts->m), "nf_conv_rqs: needs knots_len in {4, 8, 16} and cout = 3m-2 (got m=%d, cout=%d)", opts->m, cout);
+  NF_REQUIRE(nf_conv_rqs_supported(cout, opts->m) ||
+                 ((flags & NF_CONV_UNIT_INPUT) && (flags & NF_CONV_SPLIT16_INPUT) && cin == 8 &&
+                  nf_conv_rqs_split16_supported(lattice, cout, opts->m)),
+             "nf_conv_rqs: needs knots_len in {4, 8, 16} (or 2..16 on the split-fp16 chain) and cout = 3m-2 (got m=%d, cout=%d)", opts->m, cout);
   NF_REQUIRE(!opts->fixed_knots_x && !opts->fixed_knots_y, "nf_conv_rqs: fixed knots are not fused");
   NF_REQUIRE(lattice[3] % 2 == 0, "nf_conv_rqs: needs an even fastest axis");
   NF_REQUIRE(opts->xhi > opts->xlo && opts->yhi > opts->ylo, "nf_conv_rqs: empty xlim/ylim");

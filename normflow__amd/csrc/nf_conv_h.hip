@@ -54,7 +54,8 @@ __host__ __device__ constexpr int rowidx(int r) { return ((r / 9) * H1 + (r / 3)
 constexpr int NS = 21;
 constexpr int UNITS = 128;                                // active sites per box
 constexpr float kWScale = 1024.0f, kInvWScale = 1.0f / 1024.0f;      // normflow__amd/_hip.py: SPLIT16_WEIGHT_SCALE
-constexpr int C = 46, M = 16;
+constexpr int C = 46, M = 16;                            // the LARGEST logit count / knots_len (3 column tiles); a layer may have fewer:
+                                                          // cout = 3 m - 2 <= 46 at run time (columns >= cout: zero weights, never stored)
 constexpr int PTS = UNITS + 4;                            // row stride of the logit scratch in floats: +4 spreads the 16 channels a
                                                           // wave writes at once over the banks (stride 128 put them all on one)
 constexpr int PT = C * PTS * 4;                           // bytes of the logit scratch
@@ -290,14 +291,14 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int co = (((W + k) % 3) << 4) + (lane & 15);
-      okk[k] = co < C;
+      okk[k] = co < A.cout;
       ptk[k] = lds0 + ((okk[k] ? co : 0) * PTS + (g << 2)) * 4 + (k == 0 ? 2 * ITEM : (k - 1) * PT);
     }
     const int home = (((W << 4) + (lane & 15)) * PTS + (g << 2)) * 4;      // byte offset of this lane's unit quad (site tile 0) in a plane, own column tile
     f32x4 acc0;               // what slot 0 starts from
     {
       const int co = (W << 4) + (lane & 15);
-      const float b0 = (A.bias && co < C) ? static_cast<const float *>(A.bias)[co] * kWScale * in_scale : 0.f;
+      const float b0 = (A.bias && co < A.cout) ? static_cast<const float *>(A.bias)[co] * kWScale * in_scale : 0.f;
       acc0 = f32x4{b0, b0, b0, b0};
     }
     f32x4 acc[8][3];
@@ -513,9 +514,13 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
         bool pok;
         const int64_t pair = pair_of(b, o, pass, pok);
         if (pok) {
-          float *d = outp + (int64_t(b) * C) * Vh + (pair - int64_t(b) * Vh);
+          float *d = outp + (int64_t(b) * A.cout) * Vh + (pair - int64_t(b) * Vh);
+          if (A.cout == C) {
 #pragma unroll
-          for (int c = 0; c < C; ++c) d[int64_t(c) * Vh] = ptl[c * PTS + u];
+            for (int c = 0; c < C; ++c) d[int64_t(c) * Vh] = ptl[c * PTS + u];
+          } else {
+            for (int c = 0; c < A.cout; ++c) d[int64_t(c) * Vh] = ptl[c * PTS + u];
+          }
         }
       }
       (void)pidx;
@@ -532,7 +537,14 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       const float2 xv = xpre[pass];
       float val, logd;
 #if NF_H_EPI
-      rqs_site_pt<FUSE == 2>(ptl + u, A.P, offp ? xv.y : xv.x, val, logd);
+      if (A.P.m == M) {
+        rqs_site_pt<FUSE == 2>(ptl + u, A.P, offp ? xv.y : xv.x, val, logd);
+      } else {
+        // any other knots_len (2..15): the generic site function on the logit column where it lies (run-time m; the
+        // softmax numerators overwrite the consumed logits) -- fewer channels than the m = 16 the kernel is tuned for
+        LdsCol<float> colm{reinterpret_cast<float *>(const_cast<unsigned char *>(smem_h + 2 * ITEM)) + u, PTS};
+        rqs_site<float, 0, FUSE == 2>(colm, A.P, offp ? xv.y : xv.x, val, logd);
+      }
 #else
       RegCol<float, C> a;
 #pragma unroll
@@ -664,8 +676,8 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
 int conv_h_eligible(const ConvArgs &A, int fuse, int64_t *nboxes) {
   using namespace h;
   if (!option(NF_OPT_SPLIT16) || !fuse) return 0;
-  if (A.cin != 8 || A.cout != C || NF_DBG(A, 15) || NF_STAMPS(A)) return 0;
-  if (fuse != 3 && (A.P.m != M || A.P.fx || A.P.fy)) return 0;
+  if (A.cin != 8 || A.cout < 1 || A.cout > C || NF_DBG(A, 15) || NF_STAMPS(A)) return 0;
+  if (fuse != 3 && (A.P.m < 2 || A.P.m > M || A.cout != 3 * A.P.m - 2 || A.P.fx || A.P.fy)) return 0;
   for (int mu = 0; mu < 4; ++mu)
     if (A.k[mu] != 3) return 0;
   if (A.L[3] < 32 || (A.L[3] & 15)) return 0;                // whole or half segments

@@ -310,7 +310,11 @@ class RQSplineCoupling_(Coupling_):
             return None
         a = self.mask.checkerboard_parity(parity)
         n_out = net.conv_kwargs['out_channels']
-        if a is None or (n_out + 2) % 3 or not _hip.load().nf_conv_rqs_supported(n_out, (n_out + 2) // 3):
+        if a is None or (n_out + 2) % 3:
+            return None
+        # knots_len 4 / 8 / 16 fuse on every kernel; any other knots_len <= 16 only on the split-fp16 chain (nf_conv_h.hip)
+        any_kernel = bool(_hip.load().nf_conv_rqs_supported(n_out, (n_out + 2) // 3))
+        if not any_kernel and not hasattr(net, '_fuse_plan'):
             return None
         B = x_active.shape[0]
         v = x_active.reshape(B, -1)
@@ -321,7 +325,11 @@ class RQSplineCoupling_(Coupling_):
         lj = torch.empty(B, dtype=torch.float32 if v.dtype == torch.float16 else v.dtype, device=v.device)
         for b0, b1 in self._slabs(B, hidden * v.shape[1] * 4, HIDDEN_SLAB_BYTES):
             xf = x_frozen[b0:b1]
-            got = net.hidden_and_last(self.preprocess_fz(xf.float() if xf.dtype == torch.float16 else xf))
+            xin = self.preprocess_fz(xf.float() if xf.dtype == torch.float16 else xf)
+            planned = net._fuse_plan(xin) if hasattr(net, '_fuse_plan') else None
+            if planned is not None and not any_kernel and not planned[4]:
+                return None                    # this knots_len is fused by the split-fp16 chain only, and the stack does not run it
+            got = net.hidden_and_last(xin, planned=planned) if planned is not None else net.hidden_and_last(xin)
             if got is None:
                 return None
             h, last, unit, split = got

@@ -131,18 +131,54 @@ class ConvAct(torch.nn.Sequential):
                                 parity=compact_parity or 0)
         return x
 
-    def hidden_and_last(self, x, last_kind='rqs'):
-        """(hidden activations after all but the last conv, last conv module, |hidden| <= 1?, pair tensor?) when the stack
-        maps onto the MFMA kernel and the last layer has no activation; else None.  Lets a coupling fuse the last layer
-        with its own kernel: last_kind = 'rqs' (nf_conv_rqs) or 'affine' (nf_conv_affine_split16: only the split-fp16 chain)."""
+    # ---- hidden widths below 8 on the split-fp16 chain: the kernels exchange 8-channel pair tensors, so a narrower stack runs
+    # on weights zero-padded to 8 channels (padded hidden channels are act(0) and meet zero weights in the next layer)
+    def _pad8(self, conv, w, b, pad_out, pad_in):
+        co, ci = w.shape[:2]
+        no, ni = (8 if pad_out else co), (8 if pad_in else ci)
+        if (no, ni) == (co, ci):
+            return w, b
+        cache = self.__dict__.setdefault('_w8', {})
+        key = (id(conv), pad_out, pad_in)
+        ver = (w._version, w.data_ptr(), None if b is None else b._version)
+        hit = cache.get(key)
+        if hit is None or hit[0] != ver:
+            w8 = w.new_zeros((no, ni) + tuple(w.shape[2:]))
+            w8[:co, :ci] = w.detach()
+            b8 = None
+            if b is not None:
+                b8 = b.new_zeros(no)
+                b8[:co] = b.detach()
+            hit = (ver, w8, b8)
+            cache[key] = hit
+        return hit[1], hit[2]
+
+    def _fuse_plan(self, x, last_kind='rqs'):
+        """How `hidden_and_last` will run this stack on input x: (plan, x as the kernels take it, unit, split, chain), or None
+        when the stack does not map onto the MFMA kernels with a last layer without activation.  Planning only: no launch."""
         if self.conv_kwargs.get('pre_act') is not None or x.dim() - 2 != self.conv_kwargs['conv_dim']:
             return None
         plan = self._plan()
         if plan is None or plan[-1][1] != 0:
             return None
         # (weight, bias) as the kernels take them: the parameters themselves, or fp32 copies of half parameters
+        wbs = [self._wb(conv) for conv, _ in plan]
+        got = self._fuse_plan_for(x, plan, wbs, last_kind)
+        hidden = [w.shape[0] for w, _ in wbs[:-1]]
+        if ((got is None or not got[4]) and len(plan) > 2 and x.dim() == 6 and hidden and all(h == hidden[0] for h in hidden)
+                and 1 <= hidden[0] < 8 and all(w.dim() == 6 and tuple(w.shape[2:]) == (3, 3, 3, 3) for w, _ in wbs)
+                and wbs[0][0].shape[1] == 1 and wbs[0][0].dtype == torch.float32):
+            # a narrower stack: does it run the split-fp16 chain on weights zero-padded to 8 channels?
+            n = len(plan)
+            wb8 = [self._pad8(plan[i][0], w, b, pad_out=i < n - 1, pad_in=i > 0) for i, (w, b) in enumerate(wbs)]
+            got8 = self._fuse_plan_for(x, plan, wb8, last_kind)
+            if got8 is not None and got8[4]:
+                return got8
+        return got
+
+    def _fuse_plan_for(self, x, plan, wbs, last_kind):
         import types
-        plan = [(types.SimpleNamespace(weight=w, bias=b), act) for (w, b), act in ((self._wb(conv), act) for conv, act in plan)]
+        plan = [(types.SimpleNamespace(weight=w, bias=b), act) for (w, b), (_, act) in zip(wbs, plan)]
         if plan[0][0].weight.dtype == torch.float32 and x.dtype == torch.float16:
             x = x.float()
         if not _hip.conv_supported(x, plan[0][0].weight):
@@ -160,6 +196,16 @@ class ConvAct(torch.nn.Sequential):
         # when every hidden layer after the first is an 8 -> 8 layer the split-fp16 two-site kernel takes, the pairs
         # are produced once by the first layer and flow through the whole stack
         chain = split and self._split16_chain(x, plan)
+        return plan, x, unit, split, chain
+
+    def hidden_and_last(self, x, last_kind='rqs', planned=None):
+        """(hidden activations after all but the last conv, last conv module, |hidden| <= 1?, pair tensor?) when the stack
+        maps onto the MFMA kernel and the last layer has no activation; else None.  Lets a coupling fuse the last layer
+        with its own kernel: last_kind = 'rqs' (nf_conv_rqs) or 'affine' (nf_conv_affine_split16: only the split-fp16 chain)."""
+        got = planned if planned is not None else self._fuse_plan(x, last_kind)
+        if got is None:
+            return None
+        plan, x, unit, split, chain = got
         if last_kind == 'affine' and not chain:
             return None                        # the fused affine layer exists on the pair tensor only
         lat = tuple(x.shape[2:])

@@ -74,7 +74,8 @@ def test_reference_float32_outputs_sit_inside_the_conditioned_bound(golden, pari
     bj = b["b_logd"].sum(axis=(1, 2)) + CB.EPS32 * np.abs(np.asarray(z[f"{tag}/logJ"]))
     rj = (ej / bj).max()
     parity_report(tag, "ref-fp32 y/site", ry, CB.C_SITE, "largest err / site bound")
-    parity_report(tag, "ref-fp32 logJ/sample", ej.max(), CB.C_SITE * bj[np.argmax(ej / bj)])
+    iw = int(np.argmax(ej / bj))
+    parity_report(tag, "ref-fp32 logJ/sample", ej[iw], CB.C_SITE * bj[iw], "the sample with the largest err / bound")
     assert ry <= CB.C_SITE and rj <= CB.C_SITE, (tag, ry, rj)
     # the oracle in float32, site by site, both quantities
     v32, l32 = _oracle32_sites(z, tag, False)
