@@ -185,6 +185,27 @@ int nf_spline_eval(const void *v, const void *knots_x, const void *knots_y, cons
                    void *out, void *deriv, int64_t B, int64_t V, int K, int shared_x, int shared_y,
                    int shared_d, int inverse, int dtype, void *stream);
 
+/* ---- K5s: a whole RQ-spline coupling layer of a SMALL 3-D lattice in one kernel ---------
+ * Replaces, for lattices (L0, L1, 16) that fit a CU's LDS (16^3 = BASELINE config 3), the whole atom
+ * src/nn/scalar/couplings_.py:178-200: net(x_frozen) = ConvAct 1 -> 8 -> 8 -> cout (src/nn/scalar/modules.py:120-145,
+ * 3^3 circular kernels, tanh / logistic hidden activations), make_spline (:211-262), the spline map and log g
+ * (src/lib/spline/spline.py:154-287), purify and sum_density -- the hidden activations and the logits never leave the CU.
+ * x_frozen, x_active, y: (B, V) fp32 (x_frozen: zeros at the active sites; y: zeros at the frozen sites); log0 (B) or
+ * NULL, logj (B).  w1 / w2 / w3: the layers' weights scaled by 2^10 and split into fp16 (hi, lo) MFMA fragments --
+ *   w1 [hi|lo][64 lanes][8]: A operand, lane 16 g + co holds taps 8g .. 8g+7 (tap = 9 j0 + 3 j1 + j2, zero from 27 and
+ *      for co >= 8) of the single input channel;
+ *   w2 [kernel row 3 j0 + j1 (9)][hi|lo][64][8]: A operand, lane 16 g + 8 s + co holds the 8 input channels of tap g - s of
+ *      the fastest axis for output site s of a pair (zero outside 0..2);
+ *   w3 [column tile (3)][K slice (7)][hi|lo][64][8]: B operand, lane 16 g + n holds the 8 input channels of tap 4 slice + g
+ *      for logit channel 16 tile + n (zero for tap 27 and channels >= cout);
+ * b1, b2 (8), b3 (cout): fp32 biases or NULL.  Hidden widths below 8: zero-padded by the host.  cout = 3m - 2, m = 2..16.
+ * active_parity: the active site of pair (2h, 2h+1) in row (z, y) is 2h + ((active_parity + z + y) & 1).  fp32 only. */
+int nf_small3d_rqs_supported(const int32_t *lattice3, int cout, int m, int act1, int act2);
+int nf_small3d_rqs(const void *x_frozen, const void *x_active, const void *w1, const void *b1, const void *w2,
+                   const void *b2, const void *w3, const void *b3, const void *log0, void *y, void *logj,
+                   int64_t B, const int32_t *lattice3, int active_parity, int cout, int act1, int act2,
+                   const nf_rqs_opts *opts, int inverse, void *stream);
+
 /* ---- K1: affine / shift coupling --------------------------------------------
  * Replaces couplings_.py:123-139 (affine: chunk, 2 purify, abs, exp, fma, sum)
  * and :110-116 (shift).  params is (B, 2, .) = (t, s) for affine, (B, 1, .) = t

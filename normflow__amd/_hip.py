@@ -82,6 +82,9 @@ PROTOTYPES = {
     "nf_conv_wgrad_split16_supported": (_I, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I]),
     "nf_conv_wgrad_split16_workspace": (_SZ, [_I64, C.POINTER(C.c_int32), _I]),
     "nf_conv_wgrad_split16": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _P, _I, _P, _SZ, _P]),
+    "nf_small3d_rqs_supported": (_I, [C.POINTER(C.c_int32), _I, _I, _I, _I]),
+    "nf_small3d_rqs": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, C.POINTER(C.c_int32), _I, _I, _I, _I,
+                            C.POINTER(RqsOpts), _I, _P]),
     "nf_conv_rqs_supported": (_I, [_I, _I]),
     "nf_conv_rqs_split16_supported": (_I, [C.POINTER(C.c_int32), _I, _I]),
     "nf_conv_last_path": (_I, []),
@@ -1121,6 +1124,56 @@ def conv_rqs(h, weight, bias, x_active, log0, parity, opts, inverse, unit_input=
                                _ptr(y[b0:b1]), _ptr(logj[b0:b1]), b1 - b0, lat4, k4, cin, weight.shape[0],
                                int(parity), C.byref(opts), int(inverse), flags, _ptr(ws), ws.numel(), NF_F32,
                                _stream()), "nf_conv_rqs")
+    return y, logj
+
+
+# ============================================================ small 3-D lattices: one kernel per layer
+def _split_hi_lo(w):
+    w = w.float() * SPLIT16_WEIGHT_SCALE
+    hi = w.half()
+    return hi, (w - hi.float()).half()
+
+
+def pack_small3d_weights(w1, w2, w3):
+    """(8, 1, 3, 3, 3), (8, 8, 3, 3, 3), (cout <= 48, 8, 3, 3, 3) fp32 weights -> the three fragment tensors of
+    nf_small3d_rqs (include/normflow_hip.h): scaled by 2^10, split into fp16 (hi, lo)."""
+    dev = w1.device
+    cout = w3.shape[0]
+    assert tuple(w1.shape) == (8, 1, 3, 3, 3) and tuple(w2.shape) == (8, 8, 3, 3, 3) and tuple(w3.shape[1:]) == (8, 3, 3, 3) and cout <= 48
+    # w1: A operand rows = output channel (16, 8 used), K = tap (32, 27 used); lane 16 g + row holds k = 8g .. 8g+7
+    a1 = torch.zeros(16, 32, device=dev)
+    a1[:8, :27] = w1.reshape(8, 27).float()
+    p1 = torch.stack([t.reshape(16, 4, 8).permute(1, 0, 2).reshape(64, 8) for t in _split_hi_lo(a1)])            # (2, 64, 8)
+    # w2: per kernel row (j0, j1): rows = (site-in-pair s, co), K = (tap g of the pair, ci): w[co][ci][j0][j1][g - s]
+    a2 = torch.zeros(9, 16, 4, 8, device=dev)                       # row, m = 8 s + co, g, ci
+    wr = w2.float().permute(2, 3, 0, 4, 1).reshape(9, 8, 3, 8)      # (j0 j1), co, j2, ci
+    a2[:, :8, 0:3] = wr
+    a2[:, 8:, 1:4] = wr
+    p2 = torch.stack([t.permute(0, 2, 1, 3).reshape(9, 64, 8) for t in _split_hi_lo(a2)], dim=1)                  # (9, 2, 64, 8)
+    # w3: per column tile t and slice i: cols = channel 16 t + n, K = (tap 4 i + g, ci)
+    b3 = torch.zeros(48, 28, 8, device=dev)                         # channel, tap, ci
+    b3[:cout, :27] = w3.float().reshape(cout, 8, 27).permute(0, 2, 1)
+    p3 = torch.stack([t.reshape(3, 16, 7, 4, 8).permute(0, 2, 3, 1, 4).reshape(3, 7, 64, 8) for t in _split_hi_lo(b3)], dim=2)
+    return p1.contiguous(), p2.contiguous(), p3.contiguous()        # (2,64,8), (9,2,64,8), (3,7,2,64,8)
+
+
+def small3d_rqs(x_frozen, x_active, packed, biases, log0, parity, cout, acts, opts, inverse, out=None):
+    """One launch per RQ-spline coupling layer of a small 3-D lattice (nf_small3d_rqs); inference only.
+    x_frozen, x_active: (B, L0, L1, 16) fp32; packed = pack_small3d_weights(...); biases = (b1, b2, b3) fp32 or None each."""
+    _require_device(x_frozen, x_active, log0, *packed)
+    lib = load()
+    B = x_active.shape[0]
+    lat3 = (C.c_int32 * 3)(*x_active.shape[1:])
+    x_frozen, x_active = x_frozen.contiguous(), x_active.contiguous()
+    if out is None:
+        y = torch.empty_like(x_active)
+        logj = torch.empty(B, dtype=torch.float32, device=x_active.device)
+    else:
+        y, logj = out
+    b1, b2, b3 = (None if b is None else b.detach().float().contiguous() for b in biases)
+    _check(lib.nf_small3d_rqs(_ptr(x_frozen), _ptr(x_active), _ptr(packed[0]), _ptr(b1), _ptr(packed[1]), _ptr(b2),
+                              _ptr(packed[2]), _ptr(b3), _ptr(log0), _ptr(y), _ptr(logj), B, lat3, int(parity), int(cout),
+                              int(acts[0]), int(acts[1]), C.byref(opts), int(bool(inverse)), _stream()), "nf_small3d_rqs")
     return y, logj
 
 

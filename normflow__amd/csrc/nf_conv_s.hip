@@ -1,0 +1,330 @@
+// nf_conv_s.hip -- K5s: ONE kernel per coupling layer for SMALL 3-D lattices (fastest axis 16 sites, e.g. BASELINE config 3's
+// 16^3): the parameter net ConvAct 1 -> h -> h -> 3m-2 (3^3 circular kernels, h <= 8) AND the RQ-spline coupling of a sample
+// run inside one workgroup, with the sample resident in the CU's 160 KB of LDS -- the hidden activations never touch HBM and
+// there is no halo exchange at all: the periodic wrap is an address computation inside LDS.
+// Reference chain replaced (one launch per layer instead of ~160 eager ops): src/nn/scalar/modules.py:120-145 (ConvAct),
+// src/nn/scalar/couplings_.py:178-262 (atomic_forward / backward, make_spline), src/lib/spline/spline.py:154-287.
+//
+// Arithmetic: every fp32 product as THREE fp16 matrix-core products (a_hi w_hi + a_lo w_hi + a_hi w_lo, fp32 accumulate,
+// v_mfma_f32_16x16x32_f16), as in nf_conv_c / g / h.hip: the input field is split x = x_hi + x_lo (|x| < 6.5e4, beyond: NaN,
+// never silently wrong), hidden activations are tanh / logistic outputs (|h| <= 1), weights are scaled by 2^10 and split on
+// the host (checked finite and in range there).
+//
+// Shape of the computation.  A persistent workgroup of 4 waves takes samples one at a time and marches the slowest axis:
+//   step t:  A  H1[t+2] = act(conv1(x))            one 16-site lattice row per MFMA tile (weights: the A operand, 16 = 8 + 8 pad)
+//            -- barrier --
+//            B  H2[t+1] = act(conv2(H1[t .. t+2]))  two rows = 16 site PAIRS per tile, two-site columns (nf_conv_g.hip's trick):
+//                                                  9 kernel rows x 3 products = 27 MFMAs per tile
+//            -- barrier --
+//            C  logits[t] = conv3(H2[t-1 .. t+1]) at the 128 active sites of the plane: 7 K-slices of 4 taps x 8 channels,
+//               3 column tiles, 63 MFMAs per 16-site tile; then the RQ-spline map of those sites from a per-wave logit scratch
+// H1 / H2 live in rings of 4 planes of fp16 (hi, lo) pairs (16 B per site and half); the planes beyond the ends of the periodic
+// axis (-2, -1, L0, L0+1) are computed again rather than kept (+25 % of the cheap first layer, +12 % of the second).  Every wave
+// holds ALL weights in registers (62 fragments) and owns whole tiles: no cross-wave sums, two barriers per plane.
+// log|J| of a sample is summed inside its workgroup (fixed order: bitwise reproducible), no second kernel.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include "nf_conv_core.h"
+
+namespace nf {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+namespace s3 {
+constexpr int LX = 16;            // sites of the fastest axis
+constexpr int RING = 4;           // planes kept of each hidden layer
+constexpr int C = 46, M = 16;     // most logit channels / knots (3 column tiles)
+constexpr int PTS = 36;           // floats per channel row of a wave's logit scratch: 32 sites + 4 (bank spread, 16-B rows)
+constexpr int PTW = 48 * PTS * 4; // bytes of a wave's logit scratch
+constexpr float kWScale = 1024.0f, kInvWScale = 1.0f / 1024.0f;
+__host__ __device__ constexpr size_t lds_bytes(int L0, int L1) {
+  return size_t(L0) * L1 * LX * 4 + size_t(2 * RING) * L1 * LX * 32 + 4 * PTW + 64;
+}
+}  // namespace s3
+
+struct SmallArgs {
+  const float *xf, *xa;
+  float *y;
+  const float *log0;
+  float *logj;
+  const f16x8 *w1, *w2, *w3;
+  const float *b1, *b2, *b3;
+  int64_t B;
+  int L0, L1, parity, cout, act1, act2;
+  RqsParams P;
+};
+
+template <bool INV>
+__global__ __launch_bounds__(256, 1) void conv_small3d_kernel(SmallArgs A) {
+  using namespace s3;
+  extern __shared__ __align__(16) unsigned char smem_s[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, n = lane & 15;
+  const int L0 = A.L0, L1 = A.L1;
+  const int V = L0 * L1 * LX, PSITES = L1 * LX;
+  const int PB = PSITES * 32, HL = PSITES * 16;     // bytes of a plane of pairs / offset of its lo half
+  __half2 *Xs = reinterpret_cast<__half2 *>(smem_s);
+  unsigned char *H1 = smem_s + size_t(V) * 4;
+  unsigned char *H2 = H1 + RING * PB;
+  float *pt = reinterpret_cast<float *>(H2 + RING * PB) + wave * (48 * PTS);
+  double *red = reinterpret_cast<double *>(H2 + RING * PB + 4 * PTW);
+
+  // ---- all weights, for the whole launch
+  const f16x8 a1h = A.w1[lane], a1l = A.w1[64 + lane];
+  f16x8 a2h[9], a2l[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    a2h[r] = A.w2[(2 * r) * 64 + lane];
+    a2l[r] = A.w2[(2 * r + 1) * 64 + lane];
+  }
+  f16x8 b3h[7][3], b3l[7][3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      b3h[i][t] = A.w3[((t * 7 + i) * 2) * 64 + lane];
+      b3l[i][t] = A.w3[((t * 7 + i) * 2 + 1) * 64 + lane];
+    }
+  float b1v[4], b2v[4], b3v[3];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    b1v[r] = (A.b1 && g < 2) ? A.b1[4 * g + r] : 0.f;           // stage A: lane holds channels 4g .. 4g+3 of one site (g < 2)
+    b2v[r] = A.b2 ? A.b2[4 * (g & 1) + r] : 0.f;                // stage B: channels 4(g&1) .. of site 2q + (g >> 1)
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) b3v[t] = (A.b3 && 16 * t + n < A.cout) ? A.b3[16 * t + n] : 0.f;
+
+  // ---- per-lane tap tables: stage A's K index 8g + i (27 taps of the 3^3 kernel, padded to 32), stage C's 4i + g (28)
+  int tapA[8], tapC[7];            // packed (dz + 1) | (dy + 1) << 2 | (dx + 1) << 4
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = 8 * g + i;
+    tapA[i] = k < 27 ? (k / 9) | (((k / 3) % 3) << 2) | ((k % 3) << 4) : (1 | (1 << 2) | (1 << 4));
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int k = 4 * i + g;
+    tapC[i] = k < 27 ? (k / 9) | (((k / 3) % 3) << 2) | ((k % 3) << 4) : (1 | (1 << 2) | (1 << 4));
+  }
+  const int ntw = (L1 / 2 - wave + 3) / 4;                      // tiles (row pairs) of a plane this wave owns: T = wave, wave + 4, ...
+  auto wrap1 = [](int v, int L) { return v < 0 ? v + L : (v >= L ? v - L : v); };
+  auto ring = [&](int p) { return ((p + 8) & (RING - 1)) * PB; };
+
+  // ================================================================= stage A: H1[p] = act(conv1(x)), one row per tile
+  auto stageA = [&](int p) {
+    int pz = p % L0;
+    pz = pz < 0 ? pz + L0 : pz;
+    unsigned char *dst = H1 + ring(p);
+    for (int T = wave; T < L1 / 2; T += 4) {
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int yrow = 2 * T + rr;
+        f16x8 xh, xl;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int zr = wrap1(pz + (tapA[i] & 3) - 1, L0);
+          const int yr = wrap1(yrow + ((tapA[i] >> 2) & 3) - 1, L1);
+          const int xr = (n + ((tapA[i] >> 4) & 3) - 1) & (LX - 1);
+          const __half2 v = Xs[(zr * L1 + yr) * LX + xr];
+          xh[i] = static_cast<_Float16>(__low2half(v));
+          xl[i] = static_cast<_Float16>(__high2half(v));
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, xh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, xl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l, xh, acc, 0, 0, 0);
+        if (g < 2) {                // D[channel 4g + r][site n]
+          f16x4 hi, lo;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = activate(acc[r] * kInvWScale + b1v[r], A.act1);
+            hi[r] = static_cast<_Float16>(v);
+            lo[r] = static_cast<_Float16>(v - static_cast<float>(hi[r]));
+          }
+          unsigned char *d = dst + (yrow * LX + n) * 16 + g * 8;
+          *reinterpret_cast<f16x4 *>(d) = hi;
+          *reinterpret_cast<f16x4 *>(d + HL) = lo;
+        }
+      }
+    }
+  };
+
+  // ================================================================= stage B: H2[p] = act(conv2(H1[p-1 .. p+1])), 16 site pairs per tile
+  auto stageB = [&](int p) {
+    unsigned char *dst = H2 + ring(p);
+    const int rr = n >> 3, q = n & 7;
+    const int xs = (2 * q + g - 1) & (LX - 1);         // k-group g = tap g of the pair (sites 2q-1 .. 2q+2)
+    for (int T = wave; T < L1 / 2; T += 4) {
+      const int yrow = 2 * T + rr;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j0 = 0; j0 < 3; ++j0) {
+        const unsigned char *pl = H1 + ring(p + j0 - 1);
+#pragma unroll
+        for (int j1 = 0; j1 < 3; ++j1) {
+          const int yr = wrap1(yrow + j1 - 1, L1);
+          const unsigned char *src = pl + (yr * LX + xs) * 16;
+          const f16x8 fh = *reinterpret_cast<const f16x8 *>(src);
+          const f16x8 fl = *reinterpret_cast<const f16x8 *>(src + HL);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2h[3 * j0 + j1], fh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2h[3 * j0 + j1], fl, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2l[3 * j0 + j1], fh, acc, 0, 0, 0);
+        }
+      }
+      // D[(site-in-pair s, channel)][pair n]: this lane holds channels 4(g&1) .. +3 of site 2q + (g >> 1)
+      f16x4 hi, lo;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = activate(acc[r] * kInvWScale + b2v[r], A.act2);
+        hi[r] = static_cast<_Float16>(v);
+        lo[r] = static_cast<_Float16>(v - static_cast<float>(hi[r]));
+      }
+      unsigned char *d = dst + (yrow * LX + 2 * q + (g >> 1)) * 16 + (g & 1) * 8;
+      *reinterpret_cast<f16x4 *>(d) = hi;
+      *reinterpret_cast<f16x4 *>(d + HL) = lo;
+    }
+  };
+
+  // ================================================================= stage C: logits of plane z at its active sites, then the spline
+  double lacc = 0.0;
+  auto stageC = [&](int z, int64_t sbase) {
+    const int rr = n >> 3, q = n & 7;
+    int nt = 0;
+    for (int T = wave; T < L1 / 2; T += 4, ++nt) {
+      const int yrow = 2 * T + rr;
+      const int xa = 2 * q + ((A.parity + z + yrow) & 1);       // the active site of pair q in this row
+      f32x4 acc[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int yr = wrap1(yrow + ((tapC[i] >> 2) & 3) - 1, L1);
+        const int xr = (xa + ((tapC[i] >> 4) & 3) - 1) & (LX - 1);
+        const unsigned char *src = H2 + ring(z + (tapC[i] & 3) - 1) + (yr * LX + xr) * 16;
+        const f16x8 fh = *reinterpret_cast<const f16x8 *>(src);
+        const f16x8 fl = *reinterpret_cast<const f16x8 *>(src + HL);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, b3h[i][t], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, b3h[i][t], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, b3l[i][t], acc[t], 0, 0, 0);
+        }
+      }
+      // D[site 4g + r of the tile][channel 16 t + n] -> the wave's logit scratch [channel][site]
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int ch = 16 * t + n;
+        if (ch < A.cout) {
+          f32x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[t][r] * kInvWScale + b3v[t];
+          *reinterpret_cast<f32x4 *>(pt + ch * PTS + nt * 16 + 4 * g) = v;
+        }
+      }
+    }
+    // the spline map of the wave's own sites (lane u = 16 (tile index) + site of the tile)
+    const int u = lane;
+    if (u < ntw * 16) {
+      const int T = wave + 4 * (u >> 4), m_ = u & 15;
+      const int yrow = 2 * T + (m_ >> 3), qq = m_ & 7;
+      const int xsite = 2 * qq + ((A.parity + z + yrow) & 1);
+      const int64_t site = sbase + (int64_t(z) * L1 + yrow) * LX + xsite;
+      const float v = A.xa[site];
+      float val, logd;
+      if (A.P.m == M) {
+        RegCol<float, C> col;
+#pragma unroll
+        for (int c = 0; c < C; ++c) col[c] = pt[c * PTS + u];
+        rqs_site<float, M, INV>(col, A.P, v, val, logd);
+      } else {
+        LdsCol<float> col{pt + u, PTS};
+        rqs_site<float, 0, INV>(col, A.P, v, val, logd);
+      }
+      A.y[site] = val;
+      A.y[site ^ 1] = 0.f;          // the frozen site of the pair
+      lacc += double(logd);
+    }
+  };
+
+  for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
+    const int64_t sbase = b * int64_t(V);
+    for (int i = threadIdx.x; i < V; i += 256) {
+      const float v = A.xf[sbase + i];
+      const __half hi = __float2half_rn(v);
+      Xs[i] = __halves2half2(hi, __float2half_rn(v - __half2float(hi)));
+    }
+    lacc = 0.0;
+    lds_barrier();
+    for (int t = -4; t < L0; ++t) {
+      stageA(t + 2);
+      lds_barrier();
+      if (t >= -2) stageB(t + 1);
+      lds_barrier();
+      if (t >= 0) stageC(t, sbase);
+    }
+    const double tot = wave_sum(lacc);
+    if (lane == 0) red[wave] = tot;
+    lds_barrier();                  // also: every wave is done with this sample's Xs / rings
+    if (threadIdx.x == 0) A.logj[b] = float((A.log0 ? double(A.log0[b]) : 0.0) + ((red[0] + red[1]) + (red[2] + red[3])));
+    lds_barrier();
+  }
+}
+
+}  // namespace nf
+
+using namespace nf;
+
+extern "C" int nf_small3d_rqs_supported(const int32_t *lattice3, int cout, int m, int act1, int act2) {
+  if (!lattice3 || !option(NF_OPT_SPLIT16)) return 0;
+  if (m < 2 || m > s3::M || cout != 3 * m - 2) return 0;
+  if (lattice3[2] != s3::LX || lattice3[0] < 1 || lattice3[1] < 2 || (lattice3[1] & 1) || lattice3[1] > 16) return 0;   // (a wave's logit scratch holds 2 tiles)
+  if ((act1 != kActTanh && act1 != kActSigmoid) || (act2 != kActTanh && act2 != kActSigmoid)) return 0;
+  if (s3::lds_bytes(lattice3[0], lattice3[1]) > 160 * 1024) return 0;
+  return 1;
+}
+
+extern "C" int nf_small3d_rqs(const void *x_frozen, const void *x_active, const void *w1, const void *b1, const void *w2,
+                              const void *b2, const void *w3, const void *b3, const void *log0, void *y, void *logj,
+                              int64_t B, const int32_t *lattice3, int active_parity, int cout, int act1, int act2,
+                              const nf_rqs_opts *opts, int inverse, void *stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  NF_REQUIRE(opts && lattice3, "nf_small3d_rqs: NULL pointer");
+  NF_REQUIRE(B >= 0, "nf_small3d_rqs: negative batch");
+  NF_REQUIRE(nf_small3d_rqs_supported(lattice3, cout, opts->m, act1, act2),
+             "nf_small3d_rqs: needs a 3-D lattice (L0, L1 even, 16) that fits the LDS, knots_len 2..16 with cout = 3m-2, tanh / "
+             "logistic hidden activations (got %d x %d x %d, m=%d, cout=%d)", lattice3[0], lattice3[1], lattice3[2], opts->m, cout);
+  NF_REQUIRE(!opts->fixed_knots_x && !opts->fixed_knots_y, "nf_small3d_rqs: fixed knots are not fused");
+  NF_REQUIRE(opts->xhi > opts->xlo && opts->yhi > opts->ylo, "nf_small3d_rqs: empty xlim/ylim");
+  if (B == 0) return NF_OK;
+  NF_REQUIRE(x_frozen && x_active && w1 && w2 && w3 && y && logj, "nf_small3d_rqs: NULL tensor pointer");
+  SmallArgs A{};
+  A.xf = static_cast<const float *>(x_frozen); A.xa = static_cast<const float *>(x_active);
+  A.y = static_cast<float *>(y); A.log0 = static_cast<const float *>(log0); A.logj = static_cast<float *>(logj);
+  A.w1 = static_cast<const f16x8 *>(w1); A.w2 = static_cast<const f16x8 *>(w2); A.w3 = static_cast<const f16x8 *>(w3);
+  A.b1 = static_cast<const float *>(b1); A.b2 = static_cast<const float *>(b2); A.b3 = static_cast<const float *>(b3);
+  A.B = B; A.L0 = lattice3[0]; A.L1 = lattice3[1]; A.parity = active_parity & 1; A.cout = cout; A.act1 = act1; A.act2 = act2;
+  A.P.xlo = opts->xlo; A.P.xhi = opts->xhi; A.P.ylo = opts->ylo; A.P.yhi = opts->yhi;
+  A.P.fx = nullptr; A.P.fy = nullptr; A.P.m = opts->m; A.P.el = opts->extrap_left; A.P.er = opts->extrap_right;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_error("nf_small3d_rqs: no device properties"); return NF_ELAUNCH; }
+    ncu = prop.multiProcessorCount;
+  }
+  const int64_t grid = B < ncu ? B : ncu;
+  const int lds = int(s3::lds_bytes(A.L0, A.L1));
+  auto go = [&](auto kern) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -1;
+    hipLaunchKernelGGL(kern, dim3(unsigned(grid)), dim3(256), lds, stream, A);
+    return 0;
+  };
+  if ((inverse ? go(&conv_small3d_kernel<true>) : go(&conv_small3d_kernel<false>)) != 0) {
+    set_error("nf_small3d_rqs: could not configure the kernel's LDS (%d bytes)", lds);
+    return NF_ELAUNCH;
+  }
+  return check_launch("small-lattice fused layer kernel");
+}

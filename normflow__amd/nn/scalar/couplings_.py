@@ -312,6 +312,9 @@ class RQSplineCoupling_(Coupling_):
         n_out = net.conv_kwargs['out_channels']
         if a is None or (n_out + 2) % 3:
             return None
+        small = self._small3d_atom(inverse, x_active, x_frozen, a, net, log0, n_out)
+        if small is not None:
+            return small
         # knots_len 4 / 8 / 16 fuse on every kernel; any other knots_len <= 16 only on the split-fp16 chain (nf_conv_h.hip)
         any_kernel = bool(_hip.load().nf_conv_rqs_supported(n_out, (n_out + 2) // 3))
         if not any_kernel and not hasattr(net, '_fuse_plan'):
@@ -338,6 +341,25 @@ class RQSplineCoupling_(Coupling_):
                           opts, inverse, unit_input=unit, lattice=tuple(x_frozen.shape[1:]) if split else None,
                           out=(val[b0:b1], lj[b0:b1]))
         return val.reshape(x_active.shape), lj
+
+    def _small3d_atom(self, inverse, x_active, x_frozen, a, net, log0, n_out):
+        """Small 3-D lattices (L0, L1, 16) that fit a CU's LDS -- BASELINE config 3's 16^3 --: the WHOLE atom (parameter net
+        1 -> h -> h -> C and the spline coupling) is one launch of nf_small3d_rqs per slab; nothing but x and y touches HBM."""
+        if x_active.dim() != 4 or x_active.dtype != torch.float32 or not hasattr(net, 'small3d_plan'):
+            return None
+        import ctypes as C
+        lat = tuple(x_active.shape[1:])
+        plan = net.small3d_plan()
+        if plan is None:
+            return None
+        packed, biases, acts, cout = plan
+        m = (n_out + 2) // 3
+        if cout != n_out or not _hip.load().nf_small3d_rqs_supported((C.c_int32 * 3)(*lat), cout, m, acts[0], acts[1]):
+            return None
+        B = x_active.shape[0]
+        l0 = _hip._log0_tensor(log0, x_active.reshape(B, -1), B)
+        opts = _hip.make_rqs_opts(m, self.xlim, self.ylim, self.extrap, _hip.LAYOUT_PAIR)
+        return _hip.small3d_rqs(x_frozen, x_active, packed, biases, l0, a, cout, acts, opts, inverse)
 
     def make_spline(self, out):
         """The spline the net output `out` (B, C, *L) stands for (couplings_.py:211-262): an `RQSpline` whose knots and

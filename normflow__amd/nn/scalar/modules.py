@@ -218,6 +218,36 @@ class ConvAct(torch.nn.Sequential):
                                     compact=2 if ((chain and n == 0) or (split and last_hidden)) else False)
         return x, plan[-1][0], unit, split
 
+    def small3d_plan(self):
+        """The fragment-packed weights of this stack for the small-lattice fused kernel (nf_small3d_rqs: ONE launch per
+        coupling layer, the sample resident in LDS), or None when the stack is not 1 -> h -> h -> C with 3^3 circular
+        kernels, h <= 8, tanh / logistic hidden activations and fp16-range weights.  Cached per parameter version."""
+        if self.conv_kwargs.get('pre_act') is not None or self.conv_kwargs['conv_dim'] != 3:
+            return None
+        plan = self._plan()
+        ok_act = (_hip.ACT_CODES['tanh'], _hip.ACT_CODES['expit'])
+        if plan is None or len(plan) != 3 or plan[0][1] not in ok_act or plan[1][1] not in ok_act or plan[2][1] != 0:
+            return None
+        wbs = [self._wb(conv) for conv, _ in plan]
+        (w1, b1), (w2, b2), (w3, b3) = wbs
+        h = w1.shape[0]
+        if (w1.dtype != torch.float32 or not w1.is_cuda or any(tuple(w.shape[2:]) != (3, 3, 3) for w, _ in wbs) or w1.shape[1] != 1
+                or not 1 <= h <= 8 or tuple(w2.shape[:2]) != (h, h) or w3.shape[1] != h or w3.shape[0] > 46):
+            return None
+        if not all(_hip._weights_fit_fp16(w) for w, _ in wbs):
+            return None
+        ver = tuple((w._version, w.data_ptr(), None if b is None else (b._version, b.data_ptr())) for w, b in wbs)
+        hit = self.__dict__.get('_small3d')
+        if hit is None or hit[0] != ver:
+            with torch.no_grad():
+                pad = lambda w, no, ni: torch.nn.functional.pad(w.detach().float(), (0, 0, 0, 0, 0, 0, 0, ni - w.shape[1], 0, no - w.shape[0]))
+                padb = lambda b, no: None if b is None else torch.nn.functional.pad(b.detach().float(), (0, no - b.shape[0]))
+                packed = _hip.pack_small3d_weights(pad(w1, 8, 1), pad(w2, 8, 8), pad(w3, w3.shape[0], 8))
+                biases = (padb(b1, 8), padb(b2, 8), padb(b3, w3.shape[0]))
+            hit = (ver, packed, biases, (plan[0][1], plan[1][1]), int(w3.shape[0]))
+            self.__dict__['_small3d'] = hit
+        return hit[1:]
+
     @staticmethod
     def _split16_chain(x, plan):
         import ctypes as C

@@ -2085,3 +2085,59 @@ def test_config5_full_size_in_its_own_precision(parity_report):
         parity_report(f"config 5, 48^4 fp16 storage, one {kind} layer", "y: worst err / (half-ulp + 1e-5)", worst, 1.0, f"{100 * off:.2f} % of sites off by a rounding")
         parity_report(f"config 5, 48^4 fp16 storage, one {kind} layer", "logJ vs fp64 oracle", rel(lg, lo), 1e-5)
         assert worst <= 1.0 + 1e-9 and off <= 0.02 and rel(lg, lo) <= 1e-5, (kind, worst, off, rel(lg, lo))
+
+
+@pytest.mark.parametrize("shape,B,m,hidden,acts", [((16, 16, 16), 5, 16, 8, ('tanh', 'tanh')), ((4, 6, 16), 300, 16, 8, ('tanh', 'tanh')),
+                                                   ((2, 2, 16), 7, 8, 4, ('tanh', 'expit')), ((1, 4, 16), 3, 5, 8, ('expit', 'tanh')),
+                                                   ((5, 16, 16), 4, 10, 5, ('tanh', 'tanh')), ((16, 16, 16), 2, 3, 8, ('tanh', 'tanh'))])
+def test_small3d_fused_layer_vs_oracle(shape, B, m, hidden, acts, parity_report):
+    """nf_conv_s.hip (K5s): a whole RQ-spline coupling atom of a small 3-D lattice -- BASELINE config 3's 16^3 and smaller --
+    in ONE launch with the sample resident in LDS: ConvAct 1 -> h -> h -> 3m-2 on split-fp16 products + the spline.  Forward
+    and inverse against the fp64 oracle at north_star's 1e-5 (y, log|J|), against the fp32 kernels, batch order bitwise,
+    more samples than workgroups; asserts that this kernel is the one that ran."""
+    import ctypes as C
+    torch.manual_seed(7 * m + hidden)
+    Cc = 3 * m - 2
+    act_list = [acts[0], acts[1], None]
+    net = ConvAct(1, Cc, 3, conv_dim=3, hidden_sizes=[hidden, hidden], acts=act_list).to(DEV, torch.float32)
+    with torch.no_grad():
+        for p_ in list(net.parameters())[-2:]:
+            p_.mul_(0.3)
+    mask = EvenOddMask(shape=shape)
+    lim = dict(xlim=(-4.0, 4.0), ylim=(-4.0, 4.0), extrap={'left': 'linear', 'right': 'linear'})
+    cpl = RQSplineCoupling_([net, net], mask=mask, **lim).to(DEV)
+    x = 1.5 * torch.randn((B,) + shape, device=DEV, dtype=torch.float32)
+    assert net.small3d_plan() is not None
+    assert _hip.load().nf_small3d_rqs_supported((C.c_int32 * 3)(*shape), Cc, m, _hip.ACT_CODES[acts[0]], _hip.ACT_CODES[acts[1]])
+    convs = [mod for mod in net if hasattr(mod, 'weight')]
+    layers = [(c.weight.detach().double().cpu(), c.bias.detach().double().cpu()) for c in convs]
+    nb = min(B, 6)
+    for parity in (0, 1):
+        xa, xf = mask.purify(x, parity), mask.purify(x, 1 - parity)
+        l0 = torch.randn(B, device=DEV, dtype=torch.float32)
+        with torch.no_grad():
+            a = mask.checkerboard_parity(parity)
+            got = cpl._small3d_atom(False, xa, xf, a, net, l0, Cc)
+            assert got is not None, "the small-lattice fused kernel did not take this layer"
+            yf, lf = got
+            yv, lv = cpl.atomic_forward(x_active=xa, x_frozen=xf, parity=parity, net=net, log0=l0)     # the API takes the same path
+            assert torch.equal(yv, yf) and torch.equal(lv, lf)
+            with _hip.options(split16=False):
+                yu, lu = cpl.atomic_forward(x_active=xa, x_frozen=xf, parity=parity, net=net, log0=l0)
+            assert rel(yf, yu) <= 1e-5 and rel(lf, lu) <= 1e-5, (rel(yf, yu), rel(lf, lu))
+            perm = torch.randperm(B, device=DEV)
+            yp, lp = cpl._small3d_atom(False, xa[perm], xf[perm], a, net, l0[perm], Cc)
+            assert torch.equal(yp, yf[perm]) and torch.equal(lp, lf[perm])
+            xb, lb = cpl._small3d_atom(True, yf, xf, a, net, lf, Cc)
+            y2, _ = cpl._small3d_atom(False, xb, xf, a, net, l0, Cc)
+            assert rel(y2, yf) <= 2e-5, ("forward residual of the inverse", rel(y2, yf))
+        am = O.channel_mask(shape, parity)
+        assert float((yf.double().cpu() * (1 - am)).abs().max()) == 0.0            # frozen sites: exactly zero
+        out = O.conv_act(xf[:nb].double().cpu().unsqueeze(1), layers, act_list)
+        yo, lo = O.rqs_coupling_atom(xa[:nb].double().cpu(), out, am, log0=l0[:nb].double().cpu(), **lim)
+        ey, el = rel(yf[:nb], yo), rel(lf[:nb], lo)
+        parity_report(f"small3d {shape} m={m} h={hidden} p{parity}", "y / logJ vs fp64 oracle", max(ey, el), 1e-5)
+        assert ey <= 1e-5 and el <= 1e-5, (ey, el)
+        xo, _ = O.rqs_coupling_atom(yf[:nb].double().cpu(), out, am, inverse=True, log0=lf[:nb].double().cpu(), **lim)
+        # the inverse against the oracle's inverse of the SAME y: conditioned by 1/g, bounded through the forward residual above
+        assert rel(xb[:nb], xo) <= 1e-3
