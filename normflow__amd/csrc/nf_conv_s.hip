@@ -35,11 +35,13 @@ namespace s3 {
 constexpr int LX = 16;            // sites of the fastest axis
 constexpr int RING = 4;           // planes kept of each hidden layer
 constexpr int C = 46, M = 16;     // most logit channels / knots (3 column tiles)
-constexpr int PTS = 36;           // floats per channel row of a wave's logit scratch: 32 sites + 4 (bank spread, 16-B rows)
+constexpr int PTS = 68;           // floats per channel row of a wave's logit scratch: 2 planes x 32 sites + 4 (bank spread, 16-B rows)
 constexpr int PTW = 48 * PTS * 4; // bytes of a wave's logit scratch
 constexpr float kWScale = 1024.0f, kInvWScale = 1.0f / 1024.0f;
+constexpr int PX = LX + 2;        // the input field is kept with a one-site periodic halo on every axis: taps are plain offsets
+__host__ __device__ constexpr size_t x_bytes(int L0, int L1) { return ((size_t(L0 + 2) * (L1 + 2) * PX * 2 + 15) / 16) * 16; }   // one half array (hi or lo)
 __host__ __device__ constexpr size_t lds_bytes(int L0, int L1) {
-  return size_t(L0) * L1 * LX * 4 + size_t(2 * RING) * L1 * LX * 32 + 4 * PTW + 64;
+  return 2 * x_bytes(L0, L1) + size_t(2 * RING) * L1 * LX * 32 + 4 * PTW + 64;
 }
 }  // namespace s3
 
@@ -65,8 +67,10 @@ __global__ __launch_bounds__(256, 1) void conv_small3d_kernel(SmallArgs A) {
   const int L0 = A.L0, L1 = A.L1;
   const int V = L0 * L1 * LX, PSITES = L1 * LX;
   const int PB = PSITES * 32, HL = PSITES * 16;     // bytes of a plane of pairs / offset of its lo half
-  __half2 *Xs = reinterpret_cast<__half2 *>(smem_s);
-  unsigned char *H1 = smem_s + size_t(V) * 4;
+  const int PY = L1 + 2;
+  const int XB = int(x_bytes(L0, L1));
+  unsigned char *Xh = smem_s, *Xl = smem_s + XB;      // (L0+2, L1+2, 18) halfs each: x_hi, x_lo with the periodic halo
+  unsigned char *H1 = smem_s + 2 * XB;
   unsigned char *H2 = H1 + RING * PB;
   float *pt = reinterpret_cast<float *>(H2 + RING * PB) + wave * (48 * PTS);
   double *red = reinterpret_cast<double *>(H2 + RING * PB + 4 * PTW);
@@ -87,21 +91,32 @@ __global__ __launch_bounds__(256, 1) void conv_small3d_kernel(SmallArgs A) {
       b3h[i][t] = A.w3[((t * 7 + i) * 2) * 64 + lane];
       b3l[i][t] = A.w3[((t * 7 + i) * 2 + 1) * 64 + lane];
     }
-  float b1v[4], b2v[4], b3v[3];
+  // Both hidden activations are one branch-free form: act(v) = alpha * s(beta v) + gamma with the logistic function
+  // s(u) = 1 / (1 + 2^(-u log2 e))  (tanh: 2 s(2v) - 1; logistic: s(v)), evaluated on the accumulator directly:
+  // 2^(c1 * acc + c0[channel]) with the weight scale, the bias and -beta log2 e folded into c1, c0 (one FMA, v_exp_f32,
+  // v_rcp_f32, one FMA; absolute error ~1e-7 on an O(1) activation).
+  const float be1 = A.act1 == kActTanh ? 2.f : 1.f, be2 = A.act2 == kActTanh ? 2.f : 1.f;
+  const float al1 = be1, ga1 = 1.f - be1, al2 = be2, ga2 = 1.f - be2;
+  const float c11 = -be1 * Num<float>::kLog2e * kInvWScale, c12 = -be2 * Num<float>::kLog2e * kInvWScale;
+  float c01[4], c02[4], b3v[3];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    b1v[r] = (A.b1 && g < 2) ? A.b1[4 * g + r] : 0.f;           // stage A: lane holds channels 4g .. 4g+3 of one site (g < 2)
-    b2v[r] = A.b2 ? A.b2[4 * (g & 1) + r] : 0.f;                // stage B: channels 4(g&1) .. of site 2q + (g >> 1)
+    c01[r] = -be1 * Num<float>::kLog2e * ((A.b1 && g < 2) ? A.b1[4 * g + r] : 0.f);   // stage A: lane holds channels 4g .. 4g+3 of one site (g < 2)
+    c02[r] = -be2 * Num<float>::kLog2e * (A.b2 ? A.b2[4 * (g & 1) + r] : 0.f);        // stage B: channels 4(g&1) .. of site 2q + (g >> 1)
   }
+  auto act_of = [](float acc, float c1, float c0, float al, float ga) {
+    const float t = Num<float>::exp2(__builtin_fmaf(acc, c1, c0));
+    return __builtin_fmaf(al, __builtin_amdgcn_rcpf(1.f + t), ga);
+  };
 #pragma unroll
   for (int t = 0; t < 3; ++t) b3v[t] = (A.b3 && 16 * t + n < A.cout) ? A.b3[16 * t + n] : 0.f;
 
   // ---- per-lane tap tables: stage A's K index 8g + i (27 taps of the 3^3 kernel, padded to 32), stage C's 4i + g (28)
-  int tapA[8], tapC[7];            // packed (dz + 1) | (dy + 1) << 2 | (dx + 1) << 4
+  int tapA[8], tapC[7];            // tapA: byte offset of the tap in the haloed field; tapC: packed (dz + 1) | (dy + 1) << 2 | (dx + 1) << 4
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int k = 8 * g + i;
-    tapA[i] = k < 27 ? (k / 9) | (((k / 3) % 3) << 2) | ((k % 3) << 4) : (1 | (1 << 2) | (1 << 4));
+    tapA[i] = k < 27 ? (((k / 9 - 1) * PY + ((k / 3) % 3 - 1)) * PX + (k % 3 - 1)) * 2 : 0;
   }
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
@@ -122,14 +137,11 @@ __global__ __launch_bounds__(256, 1) void conv_small3d_kernel(SmallArgs A) {
       for (int rr = 0; rr < 2; ++rr) {
         const int yrow = 2 * T + rr;
         f16x8 xh, xl;
+        const int ctr = (((pz + 1) * PY + yrow + 1) * PX + n + 1) * 2;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const int zr = wrap1(pz + (tapA[i] & 3) - 1, L0);
-          const int yr = wrap1(yrow + ((tapA[i] >> 2) & 3) - 1, L1);
-          const int xr = (n + ((tapA[i] >> 4) & 3) - 1) & (LX - 1);
-          const __half2 v = Xs[(zr * L1 + yr) * LX + xr];
-          xh[i] = static_cast<_Float16>(__low2half(v));
-          xl[i] = static_cast<_Float16>(__high2half(v));
+          xh[i] = *reinterpret_cast<const _Float16 *>(Xh + ctr + tapA[i]);
+          xl[i] = *reinterpret_cast<const _Float16 *>(Xl + ctr + tapA[i]);
         }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, xh, acc, 0, 0, 0);
@@ -139,7 +151,7 @@ __global__ __launch_bounds__(256, 1) void conv_small3d_kernel(SmallArgs A) {
           f16x4 hi, lo;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float v = activate(acc[r] * kInvWScale + b1v[r], A.act1);
+            const float v = act_of(acc[r], c11, c01[r], al1, ga1);
             hi[r] = static_cast<_Float16>(v);
             lo[r] = static_cast<_Float16>(v - static_cast<float>(hi[r]));
           }
@@ -177,7 +189,7 @@ __global__ __launch_bounds__(256, 1) void conv_small3d_kernel(SmallArgs A) {
       f16x4 hi, lo;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float v = activate(acc[r] * kInvWScale + b2v[r], A.act2);
+        const float v = act_of(acc[r], c12, c02[r], al2, ga2);
         hi[r] = static_cast<_Float16>(v);
         lo[r] = static_cast<_Float16>(v - static_cast<float>(hi[r]));
       }
@@ -188,10 +200,30 @@ __global__ __launch_bounds__(256, 1) void conv_small3d_kernel(SmallArgs A) {
   };
 
   // ================================================================= stage C: logits of plane z at its active sites, then the spline
+  // The logits of two consecutive planes are collected in the wave's scratch (32 sites each) and mapped together: the
+  // spline pass is a long dependent chain, so 64 lanes cost what 32 do.  The field values of those sites are requested at
+  // the top of the step (prefetch_x), two barriers ahead of their use.
   double lacc = 0.0;
-  auto stageC = [&](int z, int64_t sbase) {
+  float xpre = 0.f;
+  int64_t spre = -1;                 // the lane's site of the coming spline pass (-1: none)
+  auto spline_due = [&](int z) { return (z & 1) || z == L0 - 1; };
+  auto prefetch_x = [&](int z, int64_t sbase) {
+    spre = -1;
+    if (z < 0 || !spline_due(z)) return;
+    const int z0 = (z & 1) ? z - 1 : z;                         // first plane of the pass (a lone last plane: z itself)
+    const int u = lane, zz = z0 + (u >> 5), ul = u & 31;
+    if (zz <= z && ul < ntw * 16) {
+      const int T = wave + 4 * (ul >> 4), m_ = ul & 15;
+      const int yrow = 2 * T + (m_ >> 3), qq = m_ & 7;
+      const int xsite = 2 * qq + ((A.parity + zz + yrow) & 1);
+      spre = sbase + (int64_t(zz) * L1 + yrow) * LX + xsite;
+      xpre = A.xa[spre];
+    }
+  };
+  auto stageC = [&](int z) {
     const int rr = n >> 3, q = n & 7;
     int nt = 0;
+    const int half = (z & 1) * 32;                              // this plane's half of the scratch rows
     for (int T = wave; T < L1 / 2; T += 4, ++nt) {
       const int yrow = 2 * T + rr;
       const int xa = 2 * q + ((A.parity + z + yrow) & 1);       // the active site of pair q in this row
@@ -220,49 +252,49 @@ __global__ __launch_bounds__(256, 1) void conv_small3d_kernel(SmallArgs A) {
           f32x4 v;
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = acc[t][r] * kInvWScale + b3v[t];
-          *reinterpret_cast<f32x4 *>(pt + ch * PTS + nt * 16 + 4 * g) = v;
+          *reinterpret_cast<f32x4 *>(pt + ch * PTS + half + nt * 16 + 4 * g) = v;
         }
       }
     }
-    // the spline map of the wave's own sites (lane u = 16 (tile index) + site of the tile)
-    const int u = lane;
-    if (u < ntw * 16) {
-      const int T = wave + 4 * (u >> 4), m_ = u & 15;
-      const int yrow = 2 * T + (m_ >> 3), qq = m_ & 7;
-      const int xsite = 2 * qq + ((A.parity + z + yrow) & 1);
-      const int64_t site = sbase + (int64_t(z) * L1 + yrow) * LX + xsite;
-      const float v = A.xa[site];
+    if (!spline_due(z)) return;
+    // the spline map of the wave's own sites of this plane and the one before (lane u: plane u >> 5, site u & 31 of it)
+    if (spre >= 0) {
+      const int u = (z & 1) ? lane : (lane & 31);               // a lone last plane sits in the first half
       float val, logd;
       if (A.P.m == M) {
         RegCol<float, C> col;
 #pragma unroll
         for (int c = 0; c < C; ++c) col[c] = pt[c * PTS + u];
-        rqs_site<float, M, INV>(col, A.P, v, val, logd);
+        rqs_site<float, M, INV>(col, A.P, xpre, val, logd);
       } else {
         LdsCol<float> col{pt + u, PTS};
-        rqs_site<float, 0, INV>(col, A.P, v, val, logd);
+        rqs_site<float, 0, INV>(col, A.P, xpre, val, logd);
       }
-      A.y[site] = val;
-      A.y[site ^ 1] = 0.f;          // the frozen site of the pair
+      A.y[spre] = val;
+      A.y[spre ^ 1] = 0.f;          // the frozen site of the pair
       lacc += double(logd);
     }
   };
 
   for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
     const int64_t sbase = b * int64_t(V);
-    for (int i = threadIdx.x; i < V; i += 256) {
-      const float v = A.xf[sbase + i];
-      const __half hi = __float2half_rn(v);
-      Xs[i] = __halves2half2(hi, __float2half_rn(v - __half2float(hi)));
+    for (int i = threadIdx.x; i < (L0 + 2) * PY * PX; i += 256) {       // the haloed copy: source site = index - 1, wrapped
+      const int hz = i / (PY * PX), rem = i - hz * (PY * PX), hy = rem / PX, hx = rem - hy * PX;
+      const int sz = wrap1(hz - 1, L0), sy = wrap1(hy - 1, L1), sx = (hx - 1) & (LX - 1);
+      const float v = A.xf[sbase + (sz * L1 + sy) * LX + sx];
+      const _Float16 hi = static_cast<_Float16>(v);
+      reinterpret_cast<_Float16 *>(Xh)[i] = hi;
+      reinterpret_cast<_Float16 *>(Xl)[i] = static_cast<_Float16>(v - static_cast<float>(hi));
     }
     lacc = 0.0;
     lds_barrier();
     for (int t = -4; t < L0; ++t) {
+      prefetch_x(t, sbase);
       stageA(t + 2);
       lds_barrier();
       if (t >= -2) stageB(t + 1);
       lds_barrier();
-      if (t >= 0) stageC(t, sbase);
+      if (t >= 0) stageC(t);
     }
     const double tot = wave_sum(lacc);
     if (lane == 0) red[wave] = tot;
