@@ -185,6 +185,28 @@ int nf_spline_eval(const void *v, const void *knots_x, const void *knots_y, cons
                    void *out, void *deriv, int64_t B, int64_t V, int K, int shared_x, int shared_y,
                    int shared_d, int inverse, int dtype, void *stream);
 
+/* ---- K5h as a differentiable node: the fused last layer + RQ-spline coupling in a TRAINING step -----------------
+ * Reference: Fitter.step (src/_normflowcore.py:275-294) differentiates couplings_.py:178-200 through autograd, which
+ * keeps the (B, 3m-2, *L) logits of every layer alive.  Here the logits never exist in memory, forward or backward:
+ *  nf_conv_rqs_split16_train = nf_conv_rqs on the split-fp16 kernel for hidden activations of unknown range:
+ *    `in` = (B, 8, V) fp32 planes (fastest axis of 32 sites) or, with in_split16, the (B, V, 16) pair tensor
+ *    nf_planes_to_split16 made of them; absmax_bits (nf_absmax_bits of the planes, or NULL = unit range): the input is /
+ *    gets scaled by the matching power of two, the logits are descaled.  wsplit: NF_WLAYOUT_SPLIT16.  y (B, V), logj (B).
+ *  nf_conv_rqs_split16_vjp: recomputes the logits in the kernel and sends the cotangents (grad_y (B, V), grad_logj (B))
+ *    back through the spline: grad_logits (B, cout, V/2) fp32 pair-compact -- the form nf_conv_wgrad_split16 /
+ *    nf_conv_dgrad_split16 read (compact_parity) -- and grad_x (B, V), zero at frozen sites.  x_point: the point on
+ *    the x axis (the forward pass's input, or the inverse pass's output).  inverse: VJP of the inverse map.
+ * knots_len 2..16, cout = 3m-2; lattices as nf_conv_rqs_split16_supported. */
+int nf_conv_rqs_split16_train(const void *in, int in_split16, const void *wsplit, const void *bias, int cout,
+                              const void *x_active, const void *log0, void *y, void *logj, int64_t B,
+                              const int32_t *lattice, int active_parity, const void *absmax_bits,
+                              const nf_rqs_opts *opts, int inverse, void *workspace, size_t workspace_bytes,
+                              void *stream);
+int nf_conv_rqs_split16_vjp(const void *in, int in_split16, const void *wsplit, const void *bias, int cout,
+                            const void *x_point, const void *grad_y, const void *grad_logj, void *grad_logits,
+                            void *grad_x, int64_t B, const int32_t *lattice, int active_parity,
+                            const void *absmax_bits, const nf_rqs_opts *opts, int inverse, void *stream);
+
 /* ---- K5s: a whole RQ-spline coupling layer of a SMALL 3-D lattice in one kernel ---------
  * Replaces, for lattices (L0, L1, 16) that fit a CU's LDS (16^3 = BASELINE config 3), the whole atom
  * src/nn/scalar/couplings_.py:178-200: net(x_frozen) = ConvAct 1 -> 8 -> 8 -> cout (src/nn/scalar/modules.py:120-145,

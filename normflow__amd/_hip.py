@@ -85,6 +85,10 @@ PROTOTYPES = {
     "nf_small3d_rqs_supported": (_I, [C.POINTER(C.c_int32), _I, _I, _I, _I]),
     "nf_small3d_rqs": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, C.POINTER(C.c_int32), _I, _I, _I, _I,
                             C.POINTER(RqsOpts), _I, _P]),
+    "nf_conv_rqs_split16_train": (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _P, _I64, C.POINTER(C.c_int32), _I, _P,
+                                       C.POINTER(RqsOpts), _I, _P, _SZ, _P]),
+    "nf_conv_rqs_split16_vjp": (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I64, C.POINTER(C.c_int32), _I, _P,
+                                     C.POINTER(RqsOpts), _I, _P]),
     "nf_conv_rqs_supported": (_I, [_I, _I]),
     "nf_conv_rqs_split16_supported": (_I, [C.POINTER(C.c_int32), _I, _I]),
     "nf_conv_last_path": (_I, []),
@@ -1037,6 +1041,88 @@ class ConvFn(torch.autograd.Function):
         if not ctx.has_bias:
             gb = None
         return gx, gw, gb, None, None, None
+
+
+def fused_last_rqs_trainable(h, weight):
+    """Does the differentiable fused node (FusedLastRqsFn) take this last layer?  h: (B, 8, *L) fp32 hidden activations."""
+    lib = load()
+    if (h.dtype != torch.float32 or h.dim() != 6 or h.shape[1] != 8 or weight.dim() != 6 or weight.shape[1] != 8
+            or tuple(weight.shape[2:]) != (3, 3, 3, 3) or weight.shape[0] > 46 or (weight.shape[0] + 2) % 3
+            or not lib.nf_get_option(OPT_SPLIT16)):
+        return False
+    lat4 = (C.c_int32 * 4)(*h.shape[2:])
+    return bool(lib.nf_conv_rqs_split16_supported(lat4, weight.shape[0], (weight.shape[0] + 2) // 3)) and _weights_fit_fp16(weight)
+
+
+class FusedLastRqsFn(torch.autograd.Function):
+    """The last ConvAct layer (8 -> 3m-2 at the active sites) and the RQ-spline coupling as ONE differentiable node on the
+    split-fp16 kernel: forward nf_conv_rqs_split16_train, backward nf_conv_rqs_split16_vjp (logits recomputed in the
+    kernel, cotangents through the spline) + the weight / input gradient kernels on the pair-compact logit cotangent.
+    The (B, 3m-2, V/2) logits are never materialised -- only their cotangent is, once, in the backward pass."""
+
+    @staticmethod
+    def _source(h, bits, lat4):
+        """The kernel's view of the hidden activations: fp32 planes for whole-row segments, else the pair tensor."""
+        if h.shape[-1] == 32:
+            return h, 0
+        B, V = h.shape[0], h[0, 0].numel()
+        src = torch.empty((1, B, V, 16), dtype=torch.float16, device=h.device)
+        _check(load().nf_planes_to_split16(_ptr(h), _ptr(src), _ptr(bits), B, 8, lat4, -1, _stream()), "nf_planes_to_split16")
+        return src, 1
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, x_active, log0, parity, opts, inverse):
+        _require_device(h, weight, bias, x_active, log0)
+        lib = load()
+        h, x_active = h.contiguous(), x_active.contiguous()
+        B, V = x_active.shape
+        lattice = tuple(h.shape[2:])
+        lat4 = (C.c_int32 * 4)(*lattice)
+        bits = absmax_bits(h)
+        src, is16 = FusedLastRqsFn._source(h, bits, lat4)
+        wsp = pack_conv_weight_split16(weight.detach().float())
+        b = None if bias is None else bias.detach().float().contiguous()
+        y = torch.empty_like(x_active)
+        logj = torch.empty(B, dtype=torch.float32, device=h.device)
+        ws = _workspace(min(B, MAX_B), V, h.device)
+        _check(lib.nf_conv_rqs_split16_train(_ptr(src), is16, _ptr(wsp), _ptr(b), weight.shape[0], _ptr(x_active), _ptr(log0),
+                                             _ptr(y), _ptr(logj), B, lat4, int(parity), _ptr(bits), C.byref(opts),
+                                             int(bool(inverse)), _ptr(ws), ws.numel(), _stream()), "nf_conv_rqs_split16_train")
+        ctx.save_for_backward(h, weight, bias, y if inverse else x_active)
+        ctx.parity, ctx.opts, ctx.inverse, ctx.has_log0 = parity, opts, inverse, log0 is not None
+        return y, logj
+
+    @staticmethod
+    def backward(ctx, gy, glogj):
+        h, weight, bias, xpt = ctx.saved_tensors
+        lib = load()
+        B, V = xpt.shape
+        lattice = tuple(h.shape[2:])
+        lat4 = (C.c_int32 * 4)(*lattice)
+        cout = weight.shape[0]
+        bits = absmax_bits(h)
+        src, is16 = FusedLastRqsFn._source(h, bits, lat4)
+        wsp = pack_conv_weight_split16(weight.detach().float())
+        b = None if bias is None else bias.detach().float().contiguous()
+        gz = torch.empty((B, cout, V // 2), dtype=torch.float32, device=h.device)
+        gx = torch.empty_like(xpt)
+        _check(lib.nf_conv_rqs_split16_vjp(_ptr(src), is16, _ptr(wsp), _ptr(b), cout, _ptr(xpt), _ptr(gy.contiguous()),
+                                           _ptr(glogj.contiguous()), _ptr(gz), _ptr(gx), B, lat4, int(ctx.parity), _ptr(bits),
+                                           C.byref(ctx.opts), int(bool(ctx.inverse)), _stream()), "nf_conv_rqs_split16_vjp")
+        gh = gw = gb = None
+        gbits = absmax_bits(gz)
+        if ctx.needs_input_grad[0]:
+            wt = weight.detach().flip([2, 3, 4, 5]).transpose(0, 1).contiguous()
+            gh = conv_input_grad_split16(gz, wt, gbits, ctx.parity, lattice, weight)
+        if ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]):
+            got = conv_weight_grad(h, gz, weight.shape[2:], gbits, ctx.parity)
+            if got is not None:
+                gw, gb = got
+        if (ctx.needs_input_grad[0] and gh is None) or ((ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and gw is None):
+            raise NormflowHipError("FusedLastRqsFn.backward: the split-fp16 gradient kernels refused a layer the forward pass took")
+        if bias is None:
+            gb = None
+        return gh, gw, gb, gx, (glogj if ctx.has_log0 else None), None, None, None
 
 
 def conv_layer(x, weight, bias, act=0, compact=False, parity=0):

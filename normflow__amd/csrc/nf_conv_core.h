@@ -72,6 +72,8 @@ struct ConvArgs {
   int wide_no, wide_llpr;   // nf_conv_pipe.hip wide staging: row blocks per wave (0 = narrow), log2(lanes per row)
   const unsigned *gscale_bits;   // nf_conv_dgrad_split16: bits of max |cotangent| the input pair tensor was scaled by (or null)
   int accumulate;                // ... add to the output planes instead of overwriting them
+  const float *gyout;            // nf_conv_rqs_vjp: cotangent of the coupling's value, (B, V) like xact
+  const float *glogj;            // ... and of its log-det, (B)
 };
 
 // The power of two that brings a tensor whose largest magnitude has the bits *absmax to [2^12, 2^13): cotangents of a mean

@@ -493,12 +493,14 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     return int64_t(b) * (A.V / 2) + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * HP + (ok ? p3 : 0);
   };
   float2 xpre[2] = {{0.f, 0.f}, {0.f, 0.f}};     // the x pairs of the item whose logits are (about to be) in pt
+  float2 gpre[2] = {{0.f, 0.f}, {0.f, 0.f}};     // FUSE 4 / 5: and the pairs of the value's cotangent
   auto prefetch_x = [&](int b, const int (&o)[4]) {
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       bool ok;
       const int64_t pr = pair_of(b, o, pass, ok);
       xpre[pass] = load_field_pair(A, pr);
+      if constexpr (FUSE >= 4) gpre[pass] = reinterpret_cast<const float2 *>(A.gyout)[pr];
     }
   };
   auto epilogue = [&](int b, const int (&o)[4], int64_t pidx) {
@@ -521,6 +523,37 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
           } else {
             for (int c = 0; c < A.cout; ++c) d[int64_t(c) * Vh] = ptl[c * PTS + u];
           }
+        }
+      }
+      (void)pidx;
+      return;
+    }
+    if constexpr (FUSE >= 4) {
+      // VJP of the fused layer's coupling (training: Fitter.step differentiates every layer, src/_normflowcore.py:275-294):
+      // the logits were recomputed by the matrix-core part above and sit in pt; the site's cotangents (value, log-det)
+      // go back through the spline (rqs_site_vjp: segment, softmax-cumsum, softplus) -- the logit column is overwritten by
+      // its cotangent and leaves pair-compact (B, C, V/2), the form the weight- and input-gradient kernels read; the
+      // field's cotangent goes where the forward pass writes y.  FUSE 4: of the forward map, 5: of the inverse.
+      float *outp = static_cast<float *>(A.out);
+      const int64_t Vh = A.V / 2;
+      const float gl = A.glogj[b];
+#pragma unroll 1
+      for (int pass = 0; pass < 2; ++pass) {
+        const int u = pass * 64 + lane;
+        const int mt = u >> 4;
+        const int offp = (A.parity + o[0] + (mt >> 2) + o[1] + ((mt >> 1) & 1) + o[2] + (mt & 1)) & 1;
+        bool pok;
+        const int64_t pair = pair_of(b, o, pass, pok);
+        const float2 xv = xpre[pass], gv = gpre[pass];
+        LdsCol<float> colv{reinterpret_cast<float *>(const_cast<unsigned char *>(smem_h + 2 * ITEM)) + u, PTS};
+        const float gin = rqs_site_vjp<float, 0, FUSE == 5>(colv, A.P, offp ? xv.y : xv.x, offp ? gv.y : gv.x, gl);
+        if (pok) {
+          float2 ov;
+          ov.x = offp ? 0.f : gin;
+          ov.y = offp ? gin : 0.f;
+          reinterpret_cast<float2 *>(A.yout)[pair] = ov;
+          float *d = outp + (int64_t(b) * A.cout) * Vh + (pair - int64_t(b) * Vh);
+          for (int c = 0; c < A.cout; ++c) d[int64_t(c) * Vh] = ptl[c * PTS + u];
         }
       }
       (void)pidx;
@@ -720,6 +753,8 @@ int launch_conv_h(const ConvArgs &A0, int64_t B, int fuse, hipStream_t stream, b
     return 1;
   };
   if (fuse == 3) return segm ? go(&conv_h_kernel<3, true>, lds_bytes<true>()) : go(&conv_h_kernel<3, false>, lds_bytes<false>());
+  if (fuse == 4) return segm ? go(&conv_h_kernel<4, true>, lds_bytes<true>()) : go(&conv_h_kernel<4, false>, lds_bytes<false>());
+  if (fuse == 5) return segm ? go(&conv_h_kernel<5, true>, lds_bytes<true>()) : go(&conv_h_kernel<5, false>, lds_bytes<false>());
   if (fuse == 1) return segm ? go(&conv_h_kernel<1, true>, lds_bytes<true>()) : go(&conv_h_kernel<1, false>, lds_bytes<false>());
   return segm ? go(&conv_h_kernel<2, true>, lds_bytes<true>()) : go(&conv_h_kernel<2, false>, lds_bytes<false>());
 }
@@ -756,4 +791,83 @@ extern "C" int nf_conv_last_logits_split16(const void *in, int in_split16, const
   if (pr == -2) { set_error("nf_conv_last_logits_split16: batch x boxes >= 2^31 work items, split the batch"); return NF_EINVAL; }
   if (pr != 1) { set_error("nf_conv_last_logits_split16: could not launch the kernel"); return NF_ELAUNCH; }
   return check_launch("conv split-fp16 logits kernel");
+}
+
+// The fused last layer + RQ-spline coupling as a DIFFERENTIABLE node of a training step (reference: Fitter.step,
+// src/_normflowcore.py:275-294, differentiates src/nn/scalar/couplings_.py:178-200 through autograd; here the logits of the
+// layer never exist in memory, forward or backward).  Shared argument block of the forward and the VJP entry.
+static int rqs_train_args(ConvArgs &A, const char *who, const void *in, int in_split16, const void *wsplit, const void *bias,
+                          int cout, const void *x, int64_t B, const int32_t *lattice, int active_parity,
+                          const void *absmax_bits, const nf_rqs_opts *opts) {
+  NF_REQUIRE(in && wsplit && x && lattice && opts, "%s: NULL pointer", who);
+  NF_REQUIRE(B >= 0, "%s: negative batch", who);
+  NF_REQUIRE(!opts->fixed_knots_x && !opts->fixed_knots_y, "%s: fixed knots are not fused", who);
+  NF_REQUIRE(opts->xhi > opts->xlo && opts->yhi > opts->ylo, "%s: empty xlim/ylim", who);
+  A.V = 1;
+  for (int mu = 0; mu < 4; ++mu) { A.L[mu] = lattice[mu]; A.k[mu] = 3; A.V *= lattice[mu]; }
+  A.in = in; A.wfrag = wsplit; A.bias = bias;
+  A.cin = 8; A.cout = cout;
+  A.parity = active_parity & 1;
+  A.in_split16 = in_split16 ? 1 : 0;
+  A.gscale_bits = static_cast<const unsigned *>(absmax_bits);
+  A.xact = static_cast<const float *>(x);
+  A.P.xlo = opts->xlo; A.P.xhi = opts->xhi; A.P.ylo = opts->ylo; A.P.yhi = opts->yhi;
+  A.P.fx = nullptr; A.P.fy = nullptr; A.P.m = opts->m; A.P.el = opts->extrap_left; A.P.er = opts->extrap_right;
+  return NF_OK;
+}
+
+extern "C" int nf_conv_rqs_split16_train(const void *in, int in_split16, const void *wsplit, const void *bias, int cout,
+                                         const void *x_active, const void *log0, void *y, void *logj, int64_t B,
+                                         const int32_t *lattice, int active_parity, const void *absmax_bits,
+                                         const nf_rqs_opts *opts, int inverse, void *workspace, size_t workspace_bytes,
+                                         void *stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ConvArgs A{};
+  const int rc = rqs_train_args(A, "nf_conv_rqs_split16_train", in, in_split16, wsplit, bias, cout, x_active, B, lattice,
+                                active_parity, absmax_bits, opts);
+  if (rc) return rc;
+  NF_REQUIRE(y && logj, "nf_conv_rqs_split16_train: NULL output");
+  if (B == 0) return NF_OK;
+  A.yout = static_cast<float *>(y);
+  A.partial = static_cast<double *>(workspace);
+  const int fuse = inverse ? 2 : 1;
+  int64_t nboxes = 0;
+  if (!conv_h_eligible(A, fuse, &nboxes)) {
+    set_error("nf_conv_rqs_split16_train: layer not supported (4-D lattice, even extents, fastest axis 32 + 16 n sites -- fp32 planes need 32 --, knots_len 2..16, cout = 3m-2)");
+    return NF_EINVAL;
+  }
+  NF_REQUIRE(workspace && workspace_bytes >= size_t(B) * size_t(nboxes) * sizeof(double),
+             "nf_conv_rqs_split16_train: workspace %zu B < %zu B needed", workspace_bytes, size_t(B) * size_t(nboxes) * sizeof(double));
+  const int pr = launch_conv_h(A, B, fuse, stream, false);
+  if (pr == -2) { set_error("nf_conv_rqs_split16_train: batch x boxes >= 2^31 work items, split the batch"); return NF_EINVAL; }
+  if (pr != 1) { set_error("nf_conv_rqs_split16_train: could not launch the kernel"); return NF_ELAUNCH; }
+  const int rl = check_launch("conv split-fp16 training forward kernel");
+  if (rl) return rl;
+  return launch_finalize<float>(A.partial, nboxes, log0, logj, B, stream);
+}
+
+extern "C" int nf_conv_rqs_split16_vjp(const void *in, int in_split16, const void *wsplit, const void *bias, int cout,
+                                       const void *x_point, const void *grad_y, const void *grad_logj, void *grad_logits,
+                                       void *grad_x, int64_t B, const int32_t *lattice, int active_parity,
+                                       const void *absmax_bits, const nf_rqs_opts *opts, int inverse, void *stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ConvArgs A{};
+  const int rc = rqs_train_args(A, "nf_conv_rqs_split16_vjp", in, in_split16, wsplit, bias, cout, x_point, B, lattice,
+                                active_parity, absmax_bits, opts);
+  if (rc) return rc;
+  NF_REQUIRE(grad_y && grad_logj && grad_logits && grad_x, "nf_conv_rqs_split16_vjp: NULL pointer");
+  if (B == 0) return NF_OK;
+  A.gyout = static_cast<const float *>(grad_y);
+  A.glogj = static_cast<const float *>(grad_logj);
+  A.out = grad_logits;
+  A.yout = static_cast<float *>(grad_x);
+  const int fuse = inverse ? 5 : 4;
+  if (!conv_h_eligible(A, fuse, nullptr)) {
+    set_error("nf_conv_rqs_split16_vjp: layer not supported (4-D lattice, even extents, fastest axis 32 + 16 n sites -- fp32 planes need 32 --, knots_len 2..16, cout = 3m-2)");
+    return NF_EINVAL;
+  }
+  const int pr = launch_conv_h(A, B, fuse, stream, false);
+  if (pr == -2) { set_error("nf_conv_rqs_split16_vjp: batch x boxes >= 2^31 work items, split the batch"); return NF_EINVAL; }
+  if (pr != 1) { set_error("nf_conv_rqs_split16_vjp: could not launch the kernel"); return NF_ELAUNCH; }
+  return check_launch("conv split-fp16 coupling VJP kernel");
 }

@@ -388,10 +388,46 @@ class RQSplineCoupling_(Coupling_):
         val, logg = self._density_slabs(x_active, x_frozen, net, 46, one_slab)
         return val, log0 + logg
 
+    def _train_fused_atom(self, inverse, x_active, x_frozen, parity, net, log0):
+        """Training (gradients required): the hidden layers run as autograd's conv nodes, the LAST layer and the spline as
+        one differentiable node on the split-fp16 kernel (`_hip.FusedLastRqsFn`): the (B, 3m-2, *L) logits are never
+        materialised, forward or backward (Fitter.step, _normflowcore.py:275-294).  None when it does not apply (then: conv
+        stack with materialised logits + nf_rqs_fwd / _vjp)."""
+        if not torch.is_grad_enabled() or not (x_active.requires_grad or x_frozen.requires_grad
+                                               or any(p.requires_grad for p in net.parameters())):
+            return None
+        if (self.channels_axis != 1 or self.knots_x is not None or self.knots_y is not None
+                or not hasattr(net, 'hidden_differentiable') or not getattr(self.mask, 'pairable', False)
+                or x_active.dtype != torch.float32 or x_active.dim() != 5 or not hasattr(self.mask, 'checkerboard_parity')):
+            return None
+        a = self.mask.checkerboard_parity(parity)
+        n_out = net.conv_kwargs['out_channels']
+        hidden = net.conv_kwargs['hidden_sizes'] or []
+        if a is None or (n_out + 2) % 3 or not hidden or hidden[-1] != 8:
+            return None
+        import ctypes as C
+        lat4 = (C.c_int32 * 4)(*x_active.shape[1:])
+        if not _hip.load().nf_conv_rqs_split16_supported(lat4, n_out, (n_out + 2) // 3):
+            return None
+        got = net.hidden_differentiable(self.preprocess_fz(x_frozen))
+        if got is None:
+            return None
+        h, w_last, b_last = got
+        if not _hip.fused_last_rqs_trainable(h, w_last):
+            return None
+        B = x_active.shape[0]
+        v = x_active.reshape(B, -1)
+        opts = _hip.make_rqs_opts((n_out + 2) // 3, self.xlim, self.ylim, self.extrap, _hip.LAYOUT_PAIR)
+        val, lj = _hip.FusedLastRqsFn.apply(h, w_last, b_last, v, _hip._log0_tensor(log0, v, B), a, opts, inverse)
+        return val.reshape(x_active.shape), lj
+
     def _atom(self, inverse, *, x_active, x_frozen, parity, net, log0=0):
         if self.propagate_density:
             return self._density_atom(inverse, x_active, x_frozen, parity, net, log0)
         fused = self._fused_atom(inverse, x_active, x_frozen, parity, net, log0)
+        if fused is not None:
+            return fused
+        fused = self._train_fused_atom(inverse, x_active, x_frozen, parity, net, log0)
         if fused is not None:
             return fused
 

@@ -289,6 +289,21 @@ class ConvAct(torch.nn.Sequential):
         out = self._run_fused(x) if self.conv_kwargs.get('pre_act') is None else None
         return out if out is not None else super().forward(x)
 
+    def hidden_differentiable(self, x):
+        """(hidden activations (B, h, *L) through autograd's ConvFn nodes, last conv's (weight, bias)) for a coupling that
+        differentiates its own fused [last layer + map] node (FusedLastRqsFn); None when the stack does not map onto the
+        MFMA kernels with a plain last layer."""
+        if self.conv_kwargs.get('pre_act') is not None or x.dim() - 2 != self.conv_kwargs['conv_dim']:
+            return None
+        plan = self._plan()
+        if plan is None or len(plan) < 2 or plan[-1][1] != 0 or plan[0][0].weight.dtype != torch.float32:
+            return None
+        if not _hip.conv_supported(x, plan[0][0].weight):
+            return None
+        for conv, act in plan[:-1]:
+            x = _hip.conv_layer(x, conv.weight, conv.bias, act)
+        return x, plan[-1][0].weight, plan[-1][0].bias
+
     def forward_active(self, x, active_parity):
         """Raw output at the ACTIVE sites only, pair-compact (B, C, V/2): the sites whose
         coordinate sum has parity `active_parity`.  None if the fused path does not apply."""

@@ -2141,3 +2141,86 @@ def test_small3d_fused_layer_vs_oracle(shape, B, m, hidden, acts, parity_report)
         xo, _ = O.rqs_coupling_atom(yf[:nb].double().cpu(), out, am, inverse=True, log0=lf[:nb].double().cpu(), **lim)
         # the inverse against the oracle's inverse of the SAME y: conditioned by 1/g, bounded through the forward residual above
         assert rel(xb[:nb], xo) <= 1e-3
+
+
+@pytest.mark.parametrize("shape,m,B", [((2, 2, 4, 32), 16, 3), ((2, 4, 2, 48), 16, 2), ((2, 2, 2, 32), 8, 4)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_fused_last_layer_spline_vjp_vs_autograd_through_oracle(shape, m, B, inverse, parity_report):
+    """Training path (Fitter.step, src/_normflowcore.py:275-294): with gradients required the last ConvAct layer and the spline
+    are ONE differentiable node (`_hip.FusedLastRqsFn`: nf_conv_rqs_split16_train forward, nf_conv_rqs_split16_vjp backward,
+    logits recomputed in the kernel and never materialised).  Values and the gradients of mean(log|J|) + mean(out^2) with
+    respect to the field and to every parameter of the net, against autograd through the fp64 oracle, and against the
+    unfused GPU path (conv stack with materialised logits + nf_rqs_*_vjp)."""
+    torch.manual_seed(3 * m + len(shape) + int(inverse))
+    Cc = 3 * m - 2
+    acts = ['tanh', 'tanh', None]
+    net = ConvAct(1, Cc, 3, conv_dim=4, hidden_sizes=[8, 8], acts=acts).to(DEV, torch.float32)
+    with torch.no_grad():
+        for p_ in list(net.parameters())[-2:]:
+            p_.mul_(0.3)
+    mask = EvenOddMask(shape=shape)
+    lim = dict(xlim=(-4.0, 4.0), ylim=(-4.0, 4.0), extrap={'left': 'linear', 'right': 'linear'})
+    cpl = RQSplineCoupling_([net, net], mask=mask, **lim).to(DEV)
+    params = list(net.parameters())
+    x = 1.3 * torch.randn((B,) + shape, device=DEV, dtype=torch.float32)
+    parity = 1
+    am = O.channel_mask(shape, parity)
+    xa0, xf0 = mask.purify(x, parity), mask.purify(x, 1 - parity)
+    l0 = torch.randn(B, device=DEV, dtype=torch.float32)
+
+    def run(fused):
+        xa, xf = xa0.clone().requires_grad_(True), xf0.clone().requires_grad_(True)
+        if fused:
+            got = cpl._train_fused_atom(inverse, xa, xf, parity, net, l0)
+            assert got is not None, "the differentiable fused node did not take this layer"
+            val, lj = got
+        else:
+            k = lambda v, p, l, act, layout: _hip.RQSCouplingFn.apply(v, p, l, act, cpl._opts(p.shape[1], layout, v), inverse)
+            val, lj = cpl._run_atom(k, xa, xf, parity, net, l0, Cc)
+        loss = lj.mean() + (val ** 2).mean()
+        grads = torch.autograd.grad(loss, [xa, xf] + params)
+        return val.detach(), lj.detach(), [g_.detach() for g_ in grads]
+
+    vf, lf, gf = run(True)
+    vu, lu, gu = run(False)
+    # the API takes the fused node by itself when gradients are required
+    xa, xf = xa0.clone().requires_grad_(True), xf0.clone()
+    fn = cpl.atomic_backward if inverse else cpl.atomic_forward
+    va, la = fn(x_active=xa, x_frozen=xf, parity=parity, net=net, log0=l0)
+    assert torch.equal(va, vf) and torch.equal(la, lf) and va.grad_fn is not None
+    # the oracle, fp64, autograd
+    with torch.device("cpu"):
+        convs = [mod for mod in net if hasattr(mod, 'weight')]
+        leaves = [(c.weight.detach().double().cpu().requires_grad_(True), c.bias.detach().double().cpu().requires_grad_(True)) for c in convs]
+        xao, xfo = xa0.double().cpu().requires_grad_(True), xf0.double().cpu().requires_grad_(True)
+        out = O.conv_act(xfo.unsqueeze(1), leaves, acts)
+        vo, lo = O.rqs_coupling_atom(xao, out, am, inverse=inverse, log0=l0.double().cpu(), **lim)
+        loss = lo.mean() + (vo ** 2).mean()
+        flat = [xao, xfo] + [t for wb in leaves for t in wb]
+        go = torch.autograd.grad(loss, flat)
+    # parameter order of the module: weight, bias per conv (Conv4d keeps its weight in the lower-dimensional container)
+    def as_module_order(glist):
+        outl = list(glist[:2])
+        k = 2
+        for c in convs:
+            outl.append((c, glist[k], glist[k + 1]))
+            k += 2
+        return outl
+    assert rel(vf, vo) <= 2e-5 and rel(lf, lo) <= 1e-5, (rel(vf, vo), rel(lf, lo))
+    names = ["grad x_active", "grad x_frozen"] + [f"grad {n_}" for n_, _ in net.named_parameters()]
+    ref = {"grad x_active": go[0], "grad x_frozen": go[1]}
+    k = 2
+    for ci, c in zip((0, 2, 4), convs):
+        ref[f"grad {ci}._conv_lower_dim.weight"] = go[k].movedim(2, 1).reshape(c._conv_lower_dim.weight.shape)
+        ref[f"grad {ci}.bias"] = go[k + 1]
+        k += 2
+    worst = 0.0
+    for name, a_, b_ in zip(names, gf, gu):
+        want = ref[name]
+        e_or, e_un = rel(a_, want) / max(1e-30, float(want.abs().max())) * max(1.0, float(want.abs().max())), rel(a_, b_)
+        scale = max(1e-30, float(want.abs().max()))
+        e_or = float((a_.double().cpu() - want).abs().max()) / scale           # relative to the gradient's own largest entry
+        e_un = float((a_ - b_).abs().max()) / scale
+        worst = max(worst, e_or)
+        assert e_or <= 2e-4 and e_un <= 2e-4, (name, e_or, e_un)
+    parity_report(f"fused VJP {shape} m={m} inverse={inverse}", "worst gradient vs oracle (rel. to its max)", worst, 2e-4)
