@@ -537,23 +537,36 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       float *outp = static_cast<float *>(A.out);
       const int64_t Vh = A.V / 2;
       const float gl = A.glogj[b];
-#pragma unroll 1
-      for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {       // (both passes in flight: two independent dependent chains)
         const int u = pass * 64 + lane;
         const int mt = u >> 4;
         const int offp = (A.parity + o[0] + (mt >> 2) + o[1] + ((mt >> 1) & 1) + o[2] + (mt & 1)) & 1;
         bool pok;
         const int64_t pair = pair_of(b, o, pass, pok);
         const float2 xv = xpre[pass], gv = gpre[pass];
-        LdsCol<float> colv{reinterpret_cast<float *>(const_cast<unsigned char *>(smem_h + 2 * ITEM)) + u, PTS};
-        const float gin = rqs_site_vjp<float, 0, FUSE == 5>(colv, A.P, offp ? xv.y : xv.x, offp ? gv.y : gv.x, gl);
+        float *d = outp + (int64_t(b) * A.cout) * Vh + (pair - int64_t(b) * Vh);
+        float gin;
+        if (A.P.m == M) {            // knots_len 16: the column in registers, cotangents straight from them to memory
+          RegCol<float, C> colr;
+#pragma unroll
+          for (int c = 0; c < C; ++c) colr[c] = ptl[c * PTS + u];
+          gin = rqs_site_vjp<float, M, FUSE == 5>(colr, A.P, offp ? xv.y : xv.x, offp ? gv.y : gv.x, gl);
+          if (pok) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) d[int64_t(c) * Vh] = colr[c];
+          }
+        } else {                     // any other knots_len: the generic form on the LDS column
+          LdsCol<float> colv{reinterpret_cast<float *>(const_cast<unsigned char *>(smem_h + 2 * ITEM)) + u, PTS};
+          gin = rqs_site_vjp<float, 0, FUSE == 5>(colv, A.P, offp ? xv.y : xv.x, offp ? gv.y : gv.x, gl);
+          if (pok)
+            for (int c = 0; c < A.cout; ++c) d[int64_t(c) * Vh] = ptl[c * PTS + u];
+        }
         if (pok) {
           float2 ov;
           ov.x = offp ? 0.f : gin;
           ov.y = offp ? gin : 0.f;
           reinterpret_cast<float2 *>(A.yout)[pair] = ov;
-          float *d = outp + (int64_t(b) * A.cout) * Vh + (pair - int64_t(b) * Vh);
-          for (int c = 0; c < A.cout; ++c) d[int64_t(c) * Vh] = ptl[c * PTS + u];
         }
       }
       (void)pidx;

@@ -22,6 +22,21 @@ PARAM_SLAB_BYTES = 6 << 30
 HIDDEN_SLAB_BYTES = 8 << 30
 
 
+# Training: an RQ-spline atom whose (B, 3m-2, V/2) logits would exceed this many bytes runs its last layer + spline as ONE
+# differentiable node that never materialises them (`_hip.FusedLastRqsFn`: -96 MB per sample and net at 32^4, +17 % step
+# time because the backward pass recomputes the layer); smaller atoms keep the faster materialising path.  0 = always fused.
+TRAIN_FUSED_MIN_LOGIT_BYTES = 1 << 30
+
+
+def set_training_fusion(min_logit_bytes):
+    """Byte threshold above which a training atom uses the logit-free fused node (0: always; a huge number: never).
+    Returns the previous threshold."""
+    global TRAIN_FUSED_MIN_LOGIT_BYTES
+    old = TRAIN_FUSED_MIN_LOGIT_BYTES
+    TRAIN_FUSED_MIN_LOGIT_BYTES = int(min_logit_bytes)
+    return old
+
+
 def set_slab_bytes(params=None, hidden=None):
     """Planner knobs of this module (the product reads no environment variable): byte budgets of the logit slab of an
     unfused atom and of the hidden-activation slab of a fused one.  Returns the previous (params, hidden)."""
@@ -405,6 +420,8 @@ class RQSplineCoupling_(Coupling_):
         hidden = net.conv_kwargs['hidden_sizes'] or []
         if a is None or (n_out + 2) % 3 or not hidden or hidden[-1] != 8:
             return None
+        if x_active.shape[0] * n_out * (x_active[0].numel() // 2) * 4 < TRAIN_FUSED_MIN_LOGIT_BYTES:
+            return None                        # small atom: the materialising path is faster (no recomputation)
         import ctypes as C
         lat4 = (C.c_int32 * 4)(*x_active.shape[1:])
         if not _hip.load().nf_conv_rqs_split16_supported(lat4, n_out, (n_out + 2) // 3):
