@@ -368,3 +368,74 @@ def test_coupling_slab_budgets_are_module_settings():
     assert (couplings_.PARAM_SLAB_BYTES, couplings_.HIDDEN_SLAB_BYTES) == old
     src = open(couplings_.__file__).read()
     assert "os.environ" not in src and "getenv" not in src
+
+
+def test_round3_entry_points_validate_their_arguments_without_gpu():
+    """The entry points added in round 3 refuse bad arguments with a status code and a message before any launch (no GPU
+    needed): nf_spline_eval, nf_small3d_rqs(+_supported), nf_conv_rqs_split16_supported, the training node's two calls."""
+    lib = _hip.load()
+    err = lambda: lib.nf_last_error_string().decode()
+    assert lib.nf_spline_eval(None, None, None, None, None, None, 1, 8, 1, 0, 0, 0, 0, 0, None) == -1 and "2 knots" in err()
+    assert lib.nf_spline_eval(None, None, None, None, None, None, 1, 8, 4, 0, 0, 0, 0, 7, None) == -1 and "dtype" in err()
+    assert lib.nf_spline_eval(None, None, None, None, None, None, 0, 8, 4, 0, 0, 0, 0, 0, None) == 0          # empty batch: nothing to do
+    assert lib.nf_spline_eval(None, None, None, None, None, None, 1, 8, 4, 0, 0, 0, 0, 0, None) == -1 and "NULL" in err()
+    lat3 = lambda *l: (ctypes.c_int32 * 3)(*l)
+    T, S = _hip.ACT_CODES['tanh'], _hip.ACT_CODES['expit']
+    assert lib.nf_small3d_rqs_supported(lat3(16, 16, 16), 46, 16, T, T) == 1
+    assert lib.nf_small3d_rqs_supported(lat3(4, 6, 16), 22, 8, T, S) == 1
+    assert lib.nf_small3d_rqs_supported(lat3(16, 16, 32), 46, 16, T, T) == 0        # fastest axis must be 16
+    assert lib.nf_small3d_rqs_supported(lat3(16, 5, 16), 46, 16, T, T) == 0         # odd middle extent
+    assert lib.nf_small3d_rqs_supported(lat3(16, 16, 16), 46, 15, T, T) == 0        # cout != 3m - 2
+    assert lib.nf_small3d_rqs_supported(lat3(16, 16, 16), 46, 16, T, 2) == 0         # relu outputs are not fp16-safe
+    assert lib.nf_small3d_rqs_supported(lat3(64, 16, 16), 46, 16, T, T) == 0        # does not fit the LDS
+    opts = _hip.make_rqs_opts(16, (-5, 5), (-5, 5), {}, _hip.LAYOUT_PAIR)
+    rc = lib.nf_small3d_rqs(None, None, None, None, None, None, None, None, None, None, None, 2, lat3(16, 16, 32), 0, 46, T, T,
+                            ctypes.byref(opts), 0, None)
+    assert rc == -1 and "3-D lattice" in err()
+    rc = lib.nf_small3d_rqs(None, None, None, None, None, None, None, None, None, None, None, 0, lat3(16, 16, 16), 0, 46, T, T,
+                            ctypes.byref(opts), 0, None)
+    assert rc == 0
+    lat4 = lambda *l: (ctypes.c_int32 * 4)(*l)
+    assert lib.nf_conv_rqs_split16_supported(lat4(4, 4, 4, 32), 28, 10) == 1
+    assert lib.nf_conv_rqs_split16_supported(lat4(4, 4, 4, 48), 46, 16) == 1
+    assert lib.nf_conv_rqs_split16_supported(lat4(4, 4, 4, 16), 46, 16) == 0
+    assert lib.nf_conv_rqs_split16_supported(lat4(4, 3, 4, 32), 46, 16) == 0
+    assert lib.nf_conv_rqs_split16_supported(lat4(4, 4, 4, 32), 49, 17) == 0
+    rc = lib.nf_conv_rqs_split16_train(None, 0, None, None, 46, None, None, None, None, 1, lat4(4, 4, 4, 32), 0, None,
+                                       ctypes.byref(opts), 0, None, 0, None)
+    assert rc == -1 and "NULL" in err()
+    rc = lib.nf_conv_rqs_split16_vjp(None, 0, None, None, 46, None, None, None, None, None, 1, lat4(4, 4, 4, 32), 0, None,
+                                     ctypes.byref(opts), 0, None)
+    assert rc == -1 and "NULL" in err()
+
+
+def test_small3d_weight_packers_match_the_documented_fragments():
+    """pack_small3d_weights against the fragment layouts include/normflow_hip.h documents for nf_small3d_rqs (hi + lo
+    reassembled): lane 16 g + row, element i of every fragment."""
+    torch.manual_seed(0)
+    w1, w2, w3 = torch.randn(8, 1, 3, 3, 3), torch.randn(8, 8, 3, 3, 3), torch.randn(40, 8, 3, 3, 3)
+    p1, p2, p3 = _hip.pack_small3d_weights(w1, w2, w3)
+    S = _hip.SPLIT16_WEIGHT_SCALE
+    r1 = (p1[0].double() + p1[1].double()) / S
+    r2 = (p2[:, 0].double() + p2[:, 1].double()) / S
+    r3 = (p3[:, :, 0].double() + p3[:, :, 1].double()) / S
+    want1 = torch.zeros(64, 8, dtype=torch.float64)
+    want2 = torch.zeros(9, 64, 8, dtype=torch.float64)
+    want3 = torch.zeros(3, 7, 64, 8, dtype=torch.float64)
+    for g in range(4):
+        for n in range(16):
+            lane = 16 * g + n
+            for i in range(8):
+                k = 8 * g + i
+                if n < 8 and k < 27:
+                    want1[lane, i] = w1.reshape(8, 27)[n, k]
+            s_, co = n // 8, n % 8
+            if 0 <= g - s_ <= 2:
+                want2[:, lane, :] = w2[co, :, :, :, g - s_].permute(1, 2, 0).reshape(9, 8)
+            for t in range(3):
+                for i in range(7):
+                    k, ch = 4 * i + g, 16 * t + n
+                    if k < 27 and ch < 40:
+                        want3[t, i, lane] = w3.reshape(40, 8, 27)[ch, :, k]
+    for got, want in ((r1, want1), (r2, want2), (r3, want3)):
+        assert float((got - want).abs().max()) <= 2e-7 * max(1.0, float(want.abs().max()))      # hi + lo carries 22 bits

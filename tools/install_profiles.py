@@ -7,8 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 ap = argparse.ArgumentParser()
-ap.add_argument("--tag", default="r02")
-ap.add_argument("--src", default=os.path.join(ROOT, "gpurun_out", "r02p"))
+ap.add_argument("--tag", default="r03")
+ap.add_argument("--src", default=os.path.join(ROOT, "gpurun_out", "r03p"))
 a = ap.parse_args()
 P, O, T = a.src, os.path.join(ROOT, "profiles"), a.tag
 csv.field_size_limit(1 << 30)
@@ -37,11 +37,18 @@ def condense(d, out):
 condense(os.path.join(P, "FETCH_SIZE"), os.path.join(O, f"{T}_pmc_fetch_size.csv"))
 condense(os.path.join(P, "WRITE_SIZE"), os.path.join(O, f"{T}_pmc_write_size.csv"))
 condense(os.path.join(P, "sq"), os.path.join(O, f"{T}_pmc_sq.csv"))
-for src, dst in (("r02_pmc_kernels.json", f"{T}_pmc_kernels.json"), ("trace/run_kernel_stats.csv", f"{T}_bench_kernel_stats.csv"),
+pmc_name = "pmc_kernels.json" if os.path.exists(os.path.join(P, "pmc_kernels.json")) else "r02_pmc_kernels.json"
+for src, dst in ((pmc_name, f"{T}_pmc_kernels.json"), ("trace/run_kernel_stats.csv", f"{T}_bench_kernel_stats.csv"),
                  ("bench_under_rocprof.json", f"{T}_bench_under_rocprof.json"), ("bench_batch128.json", f"{T}_bench_batch128.json"),
-                 ("bench.json", f"{T}_bench.json")):
-    shutil.copy(os.path.join(P, src), os.path.join(O, dst))
+                 ("bench.json", f"{T}_bench.json"), ("config_bench.txt", f"{T}_config_bench.txt"), ("c3_bench.txt", f"{T}_c3_bench.txt"),
+                 ("c3trace/run_kernel_stats.csv", f"{T}_c3_kernel_stats.csv"), ("train_bench.txt", f"{T}_train_bench.txt"),
+                 ("traintrace/run_kernel_stats.csv", f"{T}_train_kernel_stats.csv")):
+    if os.path.exists(os.path.join(P, src)):
+        shutil.copy(os.path.join(P, src), os.path.join(O, dst))
+for d, name in (("c3sq", "c3_pmc_sq"), ("c3FETCH_SIZE", "c3_pmc_fetch_size"), ("c3WRITE_SIZE", "c3_pmc_write_size")):
+    if os.path.isdir(os.path.join(P, d)):
+        condense(os.path.join(P, d), os.path.join(O, f"{T}_{name}.csv"))
 line = json.loads(open(os.path.join(P, "bench.json")).read().strip().splitlines()[-1])
-prof = json.load(open(os.path.join(P, "r02_pmc_kernels.json")))
+prof = json.load(open(os.path.join(P, pmc_name)))
 print("bench", round(line["value"], 1), "configs/s; frac", round(line["roofline"]["frac"], 3), "; sources", line["kernel_src_sha"],
       "now", bench.kernel_src_sha(), "profile", prof["kernel_src_sha"])
