@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NF_VERSION 206 /* 0.2.0 */
+#define NF_VERSION 300 /* 0.3.0 */
 
 /* NF_F16 (nf_rqs_fwd / nf_rqs_inv with knots_len 4/8/16, nf_affine_fwd / nf_affine_inv): x, params and y are IEEE half, the arithmetic is fp32 and
  * log0 / logj are fp32 ("fp16 params / fp32 log-det accumulate", BASELINE config 5). */

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert set(_hip.PROTOTYPES) == declared
-    assert _hip.load().nf_version() == 206
+    assert _hip.load().nf_version() == 300
 
 
 def test_argument_validation_without_gpu():
