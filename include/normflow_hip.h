@@ -223,6 +223,16 @@ int nf_conv_rqs_split16_vjp(const void *in, int in_split16, const void *wsplit, 
  * b1, b2 (8), b3 (cout): fp32 biases or NULL.  Hidden widths below 8: zero-padded by the host.  cout = 3m - 2, m = 2..16.
  * active_parity: the active site of pair (2h, 2h+1) in row (z, y) is 2h + ((active_parity + z + y) & 1).  fp32 only. */
 int nf_small3d_rqs_supported(const int32_t *lattice3, int cout, int m, int act1, int act2);
+/* The same kernel for the other small-lattice atoms: kind 0 = RQ-spline coupling (cout = 3m - 2), kind 1 = AFFINE coupling
+ * (couplings_.py:123-139: the net ends in (t, s), cout = 2; y = t + x e^{-|s|}, logj = log0 - sum |s|; opts may be NULL);
+ * ndim 3: lattice (L0, L1, 16); ndim 2: lattice (L1, 16) -- BASELINE config 2's 16 x 16 -- with the 3^2 kernels embedded as the
+ * middle plane (j0 = 1) of 3^3 weight tensors, zero elsewhere, packed as for nf_small3d_rqs.  In 2-D the active site of
+ * pair (2h, 2h+1) in row y is 2h + ((active_parity + y) & 1). */
+int nf_small_lattice_supported(const int32_t *lattice, int ndim, int kind, int cout, int m, int act1, int act2);
+int nf_small_lattice_coupling(int kind, const void *x_frozen, const void *x_active, const void *w1, const void *b1,
+                              const void *w2, const void *b2, const void *w3, const void *b3, const void *log0,
+                              void *y, void *logj, int64_t B, const int32_t *lattice, int ndim, int active_parity,
+                              int cout, int act1, int act2, const nf_rqs_opts *opts, int inverse, void *stream);
 int nf_small3d_rqs(const void *x_frozen, const void *x_active, const void *w1, const void *b1, const void *w2,
                    const void *b2, const void *w3, const void *b3, const void *log0, void *y, void *logj,
                    int64_t B, const int32_t *lattice3, int active_parity, int cout, int act1, int act2,

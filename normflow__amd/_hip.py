@@ -83,6 +83,9 @@ PROTOTYPES = {
     "nf_conv_wgrad_split16_workspace": (_SZ, [_I64, C.POINTER(C.c_int32), _I]),
     "nf_conv_wgrad_split16": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _P, _I, _P, _SZ, _P]),
     "nf_small3d_rqs_supported": (_I, [C.POINTER(C.c_int32), _I, _I, _I, _I]),
+    "nf_small_lattice_supported": (_I, [C.POINTER(C.c_int32), _I, _I, _I, _I, _I, _I]),
+    "nf_small_lattice_coupling": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, C.POINTER(C.c_int32), _I, _I, _I, _I, _I,
+                                       C.POINTER(RqsOpts), _I, _P]),
     "nf_small3d_rqs": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, C.POINTER(C.c_int32), _I, _I, _I, _I,
                             C.POINTER(RqsOpts), _I, _P]),
     "nf_conv_rqs_split16_train": (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _P, _I64, C.POINTER(C.c_int32), _I, _P,
@@ -1241,6 +1244,26 @@ def pack_small3d_weights(w1, w2, w3):
     b3[:cout, :27] = w3.float().reshape(cout, 8, 27).permute(0, 2, 1)
     p3 = torch.stack([t.reshape(3, 16, 7, 4, 8).permute(0, 2, 3, 1, 4).reshape(3, 7, 64, 8) for t in _split_hi_lo(b3)], dim=2)
     return p1.contiguous(), p2.contiguous(), p3.contiguous()        # (2,64,8), (9,2,64,8), (3,7,2,64,8)
+
+
+def small_lattice_coupling(kind, x_frozen, x_active, packed, biases, log0, parity, cout, acts, opts, inverse):
+    """One launch per coupling layer of a small lattice (nf_small_lattice_coupling): kind 0 RQ-spline, 1 affine;
+    x_frozen, x_active: (B, L0, L1, 16) or (B, L1, 16) fp32; inference only."""
+    _require_device(x_frozen, x_active, log0, *packed)
+    lib = load()
+    B = x_active.shape[0]
+    lat = tuple(x_active.shape[1:])
+    latc = (C.c_int32 * len(lat))(*lat)
+    x_frozen, x_active = x_frozen.contiguous(), x_active.contiguous()
+    y = torch.empty_like(x_active)
+    logj = torch.empty(B, dtype=torch.float32, device=x_active.device)
+    b1, b2, b3 = (None if b is None else b.detach().float().contiguous() for b in biases)
+    _check(lib.nf_small_lattice_coupling(int(kind), _ptr(x_frozen), _ptr(x_active), _ptr(packed[0]), _ptr(b1), _ptr(packed[1]),
+                                         _ptr(b2), _ptr(packed[2]), _ptr(b3), _ptr(log0), _ptr(y), _ptr(logj), B, latc, len(lat),
+                                         int(parity), int(cout), int(acts[0]), int(acts[1]),
+                                         C.byref(opts) if opts is not None else None, int(bool(inverse)), _stream()),
+           "nf_small_lattice_coupling")
+    return y, logj
 
 
 def small3d_rqs(x_frozen, x_active, packed, biases, log0, parity, cout, acts, opts, inverse, out=None):

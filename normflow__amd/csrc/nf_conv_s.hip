@@ -22,6 +22,11 @@
 // axis (-2, -1, L0, L0+1) are computed again rather than kept (+25 % of the cheap first layer, +12 % of the second).  Every wave
 // holds ALL weights in registers (62 fragments) and owns whole tiles: no cross-wave sums, two barriers per plane.
 // log|J| of a sample is summed inside its workgroup (fixed order: bitwise reproducible), no second kernel.
+//
+// The same kernel serves (i) the AFFINE coupling (KIND 1: the net ends in 2 channels (t, s); y = t + x e^{-|s|}, log|J| -= |s|,
+// src/nn/scalar/couplings_.py:123-139; one column tile instead of three) and (ii) 2-D lattices (L1, 16) -- BASELINE config 2's
+// 16 x 16 --: `flat` = one plane, 3^2 kernels embedded as the middle plane of 3^3 ones (zero weights elsewhere), the ring
+// slots of the absent neighbour planes zeroed once, one step A, B, C per sample.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include "nf_conv_core.h"
@@ -54,10 +59,11 @@ struct SmallArgs {
   const float *b1, *b2, *b3;
   int64_t B;
   int L0, L1, parity, cout, act1, act2;
+  int flat;                 // 2-D lattice: a single plane, no marching
   RqsParams P;
 };
 
-template <bool INV>
+template <bool INV, int KIND>      // KIND 0: RQ-spline coupling, 1: affine coupling
 __global__ __launch_bounds__(256, 1) void conv_small3d_kernel(SmallArgs A) {
   using namespace s3;
   extern __shared__ __align__(16) unsigned char smem_s[];
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(256, 1) void conv_small3d_kernel(SmallArgs A) {
   }
   f16x8 b3h[7][3], b3l[7][3];
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
+  for (int t = 0; t < (KIND == 1 ? 1 : 3); ++t)
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
       b3h[i][t] = A.w3[((t * 7 + i) * 2) * 64 + lane];
@@ -123,6 +129,7 @@ __global__ __launch_bounds__(256, 1) void conv_small3d_kernel(SmallArgs A) {
     const int k = 4 * i + g;
     tapC[i] = k < 27 ? (k / 9) | (((k / 3) % 3) << 2) | ((k % 3) << 4) : (1 | (1 << 2) | (1 << 4));
   }
+  constexpr int NT = KIND == 1 ? 1 : 3;                         // column tiles of the last layer (affine: t and s only)
   const int ntw = (L1 / 2 - wave + 3) / 4;                      // tiles (row pairs) of a plane this wave owns: T = wave, wave + 4, ...
   auto wrap1 = [](int v, int L) { return v < 0 ? v + L : (v >= L ? v - L : v); };
   auto ring = [&](int p) { return ((p + 8) & (RING - 1)) * PB; };
@@ -227,9 +234,9 @@ __global__ __launch_bounds__(256, 1) void conv_small3d_kernel(SmallArgs A) {
     for (int T = wave; T < L1 / 2; T += 4, ++nt) {
       const int yrow = 2 * T + rr;
       const int xa = 2 * q + ((A.parity + z + yrow) & 1);       // the active site of pair q in this row
-      f32x4 acc[3];
+      f32x4 acc[NT];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
         const int yr = wrap1(yrow + ((tapC[i] >> 2) & 3) - 1, L1);
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void conv_small3d_kernel(SmallArgs A) {
         const f16x8 fh = *reinterpret_cast<const f16x8 *>(src);
         const f16x8 fl = *reinterpret_cast<const f16x8 *>(src + HL);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
+        for (int t = 0; t < NT; ++t) {
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, b3h[i][t], acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, b3h[i][t], acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, b3l[i][t], acc[t], 0, 0, 0);
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(256, 1) void conv_small3d_kernel(SmallArgs A) {
       }
       // D[site 4g + r of the tile][channel 16 t + n] -> the wave's logit scratch [channel][site]
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const int ch = 16 * t + n;
         if (ch < A.cout) {
           f32x4 v;
@@ -261,7 +268,12 @@ __global__ __launch_bounds__(256, 1) void conv_small3d_kernel(SmallArgs A) {
     if (spre >= 0) {
       const int u = (z & 1) ? lane : (lane & 31);               // a lone last plane sits in the first half
       float val, logd;
-      if (A.P.m == M) {
+      if constexpr (KIND == 1) {
+        // affine coupling: (t, s) = the net's two channels; s enters as |s| (couplings_.py:123-139)
+        const float tt = pt[u], ss = fabsf(pt[PTS + u]);
+        val = INV ? (xpre - tt) * __expf(ss) : tt + xpre * __expf(-ss);
+        logd = INV ? ss : -ss;
+      } else if (A.P.m == M) {
         RegCol<float, C> col;
 #pragma unroll
         for (int c = 0; c < C; ++c) col[c] = pt[c * PTS + u];
@@ -276,6 +288,9 @@ __global__ __launch_bounds__(256, 1) void conv_small3d_kernel(SmallArgs A) {
     }
   };
 
+  if (A.flat) {                       // the ring slots of planes -1 and +1 are read (with zero weights) and never written: zero them once
+    for (int i = threadIdx.x * 16; i < 2 * RING * PB; i += 256 * 16) *reinterpret_cast<f32x4 *>(H1 + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
     const int64_t sbase = b * int64_t(V);
     for (int i = threadIdx.x; i < (L0 + 2) * PY * PX; i += 256) {       // the haloed copy: source site = index - 1, wrapped
@@ -288,6 +303,14 @@ __global__ __launch_bounds__(256, 1) void conv_small3d_kernel(SmallArgs A) {
     }
     lacc = 0.0;
     lds_barrier();
+    if (A.flat) {                     // one plane: its neighbours along the absent axis are the zeroed ring slots
+      prefetch_x(0, sbase);
+      stageA(0);
+      lds_barrier();
+      stageB(0);
+      lds_barrier();
+      stageC(0);
+    } else
     for (int t = -4; t < L0; ++t) {
       prefetch_x(t, sbase);
       stageA(t + 2);
@@ -308,43 +331,58 @@ __global__ __launch_bounds__(256, 1) void conv_small3d_kernel(SmallArgs A) {
 
 using namespace nf;
 
-extern "C" int nf_small3d_rqs_supported(const int32_t *lattice3, int cout, int m, int act1, int act2) {
-  if (!lattice3 || !option(NF_OPT_SPLIT16)) return 0;
-  if (m < 2 || m > s3::M || cout != 3 * m - 2) return 0;
-  if (lattice3[2] != s3::LX || lattice3[0] < 1 || lattice3[1] < 2 || (lattice3[1] & 1) || lattice3[1] > 16) return 0;   // (a wave's logit scratch holds 2 tiles)
+// kind: 0 RQ-spline (cout = 3m - 2), 1 affine (cout = 2); ndim 3: lattice (L0, L1, 16), ndim 2: (L1, 16)
+static int small_supported(const int32_t *lattice, int ndim, int kind, int cout, int m, int act1, int act2) {
+  if (!lattice || !option(NF_OPT_SPLIT16) || (ndim != 2 && ndim != 3)) return 0;
+  const int L0 = ndim == 3 ? lattice[0] : 1, L1 = lattice[ndim - 2], L2 = lattice[ndim - 1];
+  if (kind == 0 && (m < 2 || m > s3::M || cout != 3 * m - 2)) return 0;
+  if (kind == 1 && cout != 2) return 0;
+  if (kind != 0 && kind != 1) return 0;
+  if (L2 != s3::LX || L0 < 1 || L1 < 2 || (L1 & 1) || L1 > 16) return 0;      // (a wave's logit scratch holds 2 tiles)
   if ((act1 != kActTanh && act1 != kActSigmoid) || (act2 != kActTanh && act2 != kActSigmoid)) return 0;
-  if (s3::lds_bytes(lattice3[0], lattice3[1]) > 160 * 1024) return 0;
+  if (s3::lds_bytes(L0, L1) > 160 * 1024) return 0;
   return 1;
 }
 
-extern "C" int nf_small3d_rqs(const void *x_frozen, const void *x_active, const void *w1, const void *b1, const void *w2,
-                              const void *b2, const void *w3, const void *b3, const void *log0, void *y, void *logj,
-                              int64_t B, const int32_t *lattice3, int active_parity, int cout, int act1, int act2,
-                              const nf_rqs_opts *opts, int inverse, void *stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  NF_REQUIRE(opts && lattice3, "nf_small3d_rqs: NULL pointer");
-  NF_REQUIRE(B >= 0, "nf_small3d_rqs: negative batch");
-  NF_REQUIRE(nf_small3d_rqs_supported(lattice3, cout, opts->m, act1, act2),
-             "nf_small3d_rqs: needs a 3-D lattice (L0, L1 even, 16) that fits the LDS, knots_len 2..16 with cout = 3m-2, tanh / "
-             "logistic hidden activations (got %d x %d x %d, m=%d, cout=%d)", lattice3[0], lattice3[1], lattice3[2], opts->m, cout);
-  NF_REQUIRE(!opts->fixed_knots_x && !opts->fixed_knots_y, "nf_small3d_rqs: fixed knots are not fused");
-  NF_REQUIRE(opts->xhi > opts->xlo && opts->yhi > opts->ylo, "nf_small3d_rqs: empty xlim/ylim");
+extern "C" int nf_small3d_rqs_supported(const int32_t *lattice3, int cout, int m, int act1, int act2) {
+  return small_supported(lattice3, 3, 0, cout, m, act1, act2);
+}
+extern "C" int nf_small_lattice_supported(const int32_t *lattice, int ndim, int kind, int cout, int m, int act1, int act2) {
+  return small_supported(lattice, ndim, kind, cout, m, act1, act2);
+}
+
+static int small_launch(const char *who, int kind, const void *x_frozen, const void *x_active, const void *w1, const void *b1,
+                        const void *w2, const void *b2, const void *w3, const void *b3, const void *log0, void *y, void *logj,
+                        int64_t B, const int32_t *lattice, int ndim, int active_parity, int cout, int act1, int act2,
+                        const nf_rqs_opts *opts, int inverse, hipStream_t stream) {
+  NF_REQUIRE(lattice && (kind == 1 || opts), "%s: NULL pointer", who);
+  NF_REQUIRE(B >= 0, "%s: negative batch", who);
+  NF_REQUIRE(small_supported(lattice, ndim, kind, cout, kind == 0 ? opts->m : 0, act1, act2),
+             "%s: needs a lattice (L0, L1 even <= 16, 16) or (L1 even <= 16, 16) that fits the LDS, %s, tanh / logistic hidden "
+             "activations (got ndim=%d, cout=%d)", who, kind == 0 ? "knots_len 2..16 with cout = 3m-2" : "cout = 2", ndim, cout);
+  if (kind == 0) {
+    NF_REQUIRE(!opts->fixed_knots_x && !opts->fixed_knots_y, "%s: fixed knots are not fused", who);
+    NF_REQUIRE(opts->xhi > opts->xlo && opts->yhi > opts->ylo, "%s: empty xlim/ylim", who);
+  }
   if (B == 0) return NF_OK;
-  NF_REQUIRE(x_frozen && x_active && w1 && w2 && w3 && y && logj, "nf_small3d_rqs: NULL tensor pointer");
+  NF_REQUIRE(x_frozen && x_active && w1 && w2 && w3 && y && logj, "%s: NULL tensor pointer", who);
   SmallArgs A{};
   A.xf = static_cast<const float *>(x_frozen); A.xa = static_cast<const float *>(x_active);
   A.y = static_cast<float *>(y); A.log0 = static_cast<const float *>(log0); A.logj = static_cast<float *>(logj);
   A.w1 = static_cast<const f16x8 *>(w1); A.w2 = static_cast<const f16x8 *>(w2); A.w3 = static_cast<const f16x8 *>(w3);
   A.b1 = static_cast<const float *>(b1); A.b2 = static_cast<const float *>(b2); A.b3 = static_cast<const float *>(b3);
-  A.B = B; A.L0 = lattice3[0]; A.L1 = lattice3[1]; A.parity = active_parity & 1; A.cout = cout; A.act1 = act1; A.act2 = act2;
-  A.P.xlo = opts->xlo; A.P.xhi = opts->xhi; A.P.ylo = opts->ylo; A.P.yhi = opts->yhi;
-  A.P.fx = nullptr; A.P.fy = nullptr; A.P.m = opts->m; A.P.el = opts->extrap_left; A.P.er = opts->extrap_right;
+  A.B = B; A.L0 = ndim == 3 ? lattice[0] : 1; A.L1 = lattice[ndim - 2]; A.flat = ndim == 2 ? 1 : 0;
+  A.parity = active_parity & 1; A.cout = cout; A.act1 = act1; A.act2 = act2;
+  if (kind == 0) {
+    A.P.xlo = opts->xlo; A.P.xhi = opts->xhi; A.P.ylo = opts->ylo; A.P.yhi = opts->yhi;
+    A.P.fx = nullptr; A.P.fy = nullptr; A.P.m = opts->m; A.P.el = opts->extrap_left; A.P.er = opts->extrap_right;
+  }
   static int ncu = 0;
   if (!ncu) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_error("nf_small3d_rqs: no device properties"); return NF_ELAUNCH; }
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_error("%s: no device properties", who); return NF_ELAUNCH; }
     ncu = prop.multiProcessorCount;
   }
   const int64_t grid = B < ncu ? B : ncu;
@@ -354,9 +392,28 @@ extern "C" int nf_small3d_rqs(const void *x_frozen, const void *x_active, const 
     hipLaunchKernelGGL(kern, dim3(unsigned(grid)), dim3(256), lds, stream, A);
     return 0;
   };
-  if ((inverse ? go(&conv_small3d_kernel<true>) : go(&conv_small3d_kernel<false>)) != 0) {
-    set_error("nf_small3d_rqs: could not configure the kernel's LDS (%d bytes)", lds);
+  int rc;
+  if (kind == 0) rc = inverse ? go(&conv_small3d_kernel<true, 0>) : go(&conv_small3d_kernel<false, 0>);
+  else rc = inverse ? go(&conv_small3d_kernel<true, 1>) : go(&conv_small3d_kernel<false, 1>);
+  if (rc != 0) {
+    set_error("%s: could not configure the kernel's LDS (%d bytes)", who, lds);
     return NF_ELAUNCH;
   }
   return check_launch("small-lattice fused layer kernel");
+}
+
+extern "C" int nf_small3d_rqs(const void *x_frozen, const void *x_active, const void *w1, const void *b1, const void *w2,
+                              const void *b2, const void *w3, const void *b3, const void *log0, void *y, void *logj,
+                              int64_t B, const int32_t *lattice3, int active_parity, int cout, int act1, int act2,
+                              const nf_rqs_opts *opts, int inverse, void *stream) {
+  return small_launch("nf_small3d_rqs", 0, x_frozen, x_active, w1, b1, w2, b2, w3, b3, log0, y, logj, B, lattice3, 3,
+                      active_parity, cout, act1, act2, opts, inverse, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int nf_small_lattice_coupling(int kind, const void *x_frozen, const void *x_active, const void *w1, const void *b1,
+                                         const void *w2, const void *b2, const void *w3, const void *b3, const void *log0,
+                                         void *y, void *logj, int64_t B, const int32_t *lattice, int ndim, int active_parity,
+                                         int cout, int act1, int act2, const nf_rqs_opts *opts, int inverse, void *stream) {
+  return small_launch("nf_small_lattice_coupling", kind, x_frozen, x_active, w1, b1, w2, b2, w3, b3, log0, y, logj, B, lattice,
+                      ndim, active_parity, cout, act1, act2, opts, inverse, static_cast<hipStream_t>(stream));
 }

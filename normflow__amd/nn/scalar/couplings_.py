@@ -178,6 +178,33 @@ class Coupling_(Module_, ABC):
             out = out.movedim(self.channels_axis, 1)
         return out.reshape(out.shape[0], out.shape[1], -1), _hip.LAYOUT_FULL
 
+    def _small_lattice_atom(self, kind, inverse, x_active, x_frozen, parity, net, log0, opts=None):
+        """Small lattices (L0, L1 <= 16, 16) or (L1 <= 16, 16) that fit a CU's LDS -- BASELINE configs 3 (16^3) and 2 (16^2) --:
+        the WHOLE atom (parameter net 1 -> h -> h -> C and the coupling, kind 0 RQ-spline / 1 affine) is ONE launch of
+        nf_small_lattice_coupling; nothing but x and y touches HBM.  None when it does not apply."""
+        if (torch.is_grad_enabled() and (x_active.requires_grad or x_frozen.requires_grad
+                                         or any(p.requires_grad for p in net.parameters()))):
+            return None
+        if (self.propagate_density or self.channels_axis != 1 or x_active.dim() not in (3, 4) or x_active.dtype != torch.float32
+                or not hasattr(net, 'small3d_plan') or not getattr(self.mask, 'pairable', False)
+                or not hasattr(self.mask, 'checkerboard_parity')):
+            return None
+        a = self.mask.checkerboard_parity(parity)
+        if a is None:
+            return None
+        plan = net.small3d_plan()
+        if plan is None:
+            return None
+        import ctypes as C
+        packed, biases, acts, cout = plan
+        lat = tuple(x_active.shape[1:])
+        m = opts.m if opts is not None else 0
+        if not _hip.load().nf_small_lattice_supported((C.c_int32 * len(lat))(*lat), len(lat), kind, cout, m, acts[0], acts[1]):
+            return None
+        B = x_active.shape[0]
+        l0 = _hip._log0_tensor(log0, x_active.reshape(B, -1), B)
+        return _hip.small_lattice_coupling(kind, x_frozen, x_active, packed, biases, l0, a, cout, acts, opts, inverse)
+
     def _slabs(self, B, per_sample_bytes, budget=None):
         step = max(1, min(B, (budget or PARAM_SLAB_BYTES) // max(1, per_sample_bytes)))
         return [(b0, min(B, b0 + step)) for b0 in range(0, B, step)]
@@ -260,6 +287,8 @@ class AffineCoupling_(Coupling_):
         if self.propagate_density:
             return self._affine_density_atom(inverse, x_active, x_frozen, parity, net, log0)
         fused = self._fused_atom(inverse, x_active, x_frozen, parity, net, log0)
+        if fused is None and getattr(net, 'conv_kwargs', {}).get('out_channels') == 2:
+            fused = self._small_lattice_atom(1, inverse, x_active, x_frozen, parity, net, log0)
         if fused is not None:
             return fused
         k = lambda v, p, l0, act, layout: _hip.AffineCouplingFn.apply(v, p, l0, act, layout, inverse)
@@ -328,6 +357,9 @@ class RQSplineCoupling_(Coupling_):
         if a is None or (n_out + 2) % 3:
             return None
         small = self._small3d_atom(inverse, x_active, x_frozen, a, net, log0, n_out)
+        if small is None and x_active.dim() == 3:           # 2-D lattices (L1, 16): the same kernel, one plane
+            small = self._small_lattice_atom(0, inverse, x_active, x_frozen, parity, net, log0,
+                                             _hip.make_rqs_opts((n_out + 2) // 3, self.xlim, self.ylim, self.extrap, _hip.LAYOUT_PAIR))
         if small is not None:
             return small
         # knots_len 4 / 8 / 16 fuse on every kernel; any other knots_len <= 16 only on the split-fp16 chain (nf_conv_h.hip)

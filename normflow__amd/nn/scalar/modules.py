@@ -219,10 +219,12 @@ class ConvAct(torch.nn.Sequential):
         return x, plan[-1][0], unit, split
 
     def small3d_plan(self):
-        """The fragment-packed weights of this stack for the small-lattice fused kernel (nf_small3d_rqs: ONE launch per
-        coupling layer, the sample resident in LDS), or None when the stack is not 1 -> h -> h -> C with 3^3 circular
-        kernels, h <= 8, tanh / logistic hidden activations and fp16-range weights.  Cached per parameter version."""
-        if self.conv_kwargs.get('pre_act') is not None or self.conv_kwargs['conv_dim'] != 3:
+        """The fragment-packed weights of this stack for the small-lattice fused kernel (nf_small3d_rqs /
+        nf_small_lattice_coupling: ONE launch per coupling layer, the sample resident in LDS), or None when the stack is not
+        1 -> h -> h -> C with 3^3 (or, on 2-D lattices, 3^2) circular kernels, h <= 8, tanh / logistic hidden activations and
+        fp16-range weights.  Cached per parameter version."""
+        cd = self.conv_kwargs['conv_dim']
+        if self.conv_kwargs.get('pre_act') is not None or cd not in (2, 3):
             return None
         plan = self._plan()
         ok_act = (_hip.ACT_CODES['tanh'], _hip.ACT_CODES['expit'])
@@ -231,7 +233,7 @@ class ConvAct(torch.nn.Sequential):
         wbs = [self._wb(conv) for conv, _ in plan]
         (w1, b1), (w2, b2), (w3, b3) = wbs
         h = w1.shape[0]
-        if (w1.dtype != torch.float32 or not w1.is_cuda or any(tuple(w.shape[2:]) != (3, 3, 3) for w, _ in wbs) or w1.shape[1] != 1
+        if (w1.dtype != torch.float32 or not w1.is_cuda or any(tuple(w.shape[2:]) != (3,) * cd for w, _ in wbs) or w1.shape[1] != 1
                 or not 1 <= h <= 8 or tuple(w2.shape[:2]) != (h, h) or w3.shape[1] != h or w3.shape[0] > 46):
             return None
         if not all(_hip._weights_fit_fp16(w) for w, _ in wbs):
@@ -240,7 +242,13 @@ class ConvAct(torch.nn.Sequential):
         hit = self.__dict__.get('_small3d')
         if hit is None or hit[0] != ver:
             with torch.no_grad():
-                pad = lambda w, no, ni: torch.nn.functional.pad(w.detach().float(), (0, 0, 0, 0, 0, 0, 0, ni - w.shape[1], 0, no - w.shape[0]))
+                def pad(w, no, ni):
+                    w = w.detach().float()
+                    if cd == 2:                # a 3^2 kernel = the middle plane of a 3^3 one
+                        w3 = w.new_zeros(tuple(w.shape[:2]) + (3, 3, 3))
+                        w3[:, :, 1] = w
+                        w = w3
+                    return torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, ni - w.shape[1], 0, no - w.shape[0]))
                 padb = lambda b, no: None if b is None else torch.nn.functional.pad(b.detach().float(), (0, no - b.shape[0]))
                 packed = _hip.pack_small3d_weights(pad(w1, 8, 1), pad(w2, 8, 8), pad(w3, w3.shape[0], 8))
                 biases = (padb(b1, 8), padb(b2, 8), padb(b3, w3.shape[0]))

@@ -391,10 +391,19 @@ def test_round3_entry_points_validate_their_arguments_without_gpu():
     opts = _hip.make_rqs_opts(16, (-5, 5), (-5, 5), {}, _hip.LAYOUT_PAIR)
     rc = lib.nf_small3d_rqs(None, None, None, None, None, None, None, None, None, None, None, 2, lat3(16, 16, 32), 0, 46, T, T,
                             ctypes.byref(opts), 0, None)
-    assert rc == -1 and "3-D lattice" in err()
+    assert rc == -1 and "needs a lattice" in err()
     rc = lib.nf_small3d_rqs(None, None, None, None, None, None, None, None, None, None, None, 0, lat3(16, 16, 16), 0, 46, T, T,
                             ctypes.byref(opts), 0, None)
     assert rc == 0
+    lat2 = lambda *l: (ctypes.c_int32 * 2)(*l)
+    assert lib.nf_small_lattice_supported(lat2(16, 16), 2, 1, 2, 0, T, T) == 1           # config 2: 16 x 16, affine
+    assert lib.nf_small_lattice_supported(lat2(16, 16), 2, 0, 22, 8, T, T) == 1          # 2-D spline
+    assert lib.nf_small_lattice_supported(lat3(8, 8, 16), 3, 1, 2, 0, T, S) == 1         # 3-D affine
+    assert lib.nf_small_lattice_supported(lat2(16, 16), 2, 1, 3, 0, T, T) == 0           # affine nets end in (t, s)
+    assert lib.nf_small_lattice_supported(lat2(16, 32), 2, 1, 2, 0, T, T) == 0
+    rc = lib.nf_small_lattice_coupling(1, None, None, None, None, None, None, None, None, None, None, None, 3, lat2(16, 16), 2, 0, 2,
+                                       T, T, None, 0, None)
+    assert rc == -1 and "NULL tensor" in err()
     lat4 = lambda *l: (ctypes.c_int32 * 4)(*l)
     assert lib.nf_conv_rqs_split16_supported(lat4(4, 4, 4, 32), 28, 10) == 1
     assert lib.nf_conv_rqs_split16_supported(lat4(4, 4, 4, 48), 46, 16) == 1

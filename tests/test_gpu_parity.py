@@ -2232,3 +2232,59 @@ def test_fused_last_layer_spline_vjp_vs_autograd_through_oracle(shape, m, B, inv
         worst = max(worst, e_or)
         assert e_or <= 2e-4 and e_un <= 2e-4, (name, e_or, e_un)
     parity_report(f"fused VJP {shape} m={m} inverse={inverse}", "worst gradient vs oracle (rel. to its max)", worst, 2e-4)
+
+
+@pytest.mark.parametrize("shape,B,kind,m,hidden", [((16, 16), 512, 'affine', 0, 8), ((16, 16), 9, 'rqs', 16, 8), ((6, 16), 300, 'affine', 0, 4),
+                                                   ((4, 16), 5, 'rqs', 8, 5), ((16, 16, 16), 3, 'affine', 0, 8), ((3, 8, 16), 7, 'affine', 0, 8)])
+def test_small_lattice_affine_and_2d_vs_oracle(shape, B, kind, m, hidden, parity_report):
+    """K5s (nf_small_lattice_coupling) beyond the 3-D spline atom: the AFFINE coupling (couplings_.py:123-139) and 2-D lattices
+    (BASELINE config 2: 16 x 16, affine, batch 512) -- the whole atom, parameter net included, in one launch.  Forward and
+    inverse against the fp64 oracle at 1e-5, against the fp32 kernels, batch order bitwise, frozen sites exactly zero; and the
+    API (`atomic_forward`) takes this path by itself."""
+    torch.manual_seed(11 * len(shape) + hidden + m)
+    d = len(shape)
+    Cc = 2 if kind == 'affine' else 3 * m - 2
+    acts = ['tanh', 'tanh', None]
+    net = ConvAct(1, Cc, 3, conv_dim=d, hidden_sizes=[hidden, hidden], acts=acts).to(DEV, torch.float32)
+    with torch.no_grad():
+        for p_ in list(net.parameters())[-2:]:
+            p_.mul_(0.3)
+    mask = EvenOddMask(shape=shape)
+    lim = dict(xlim=(-4.0, 4.0), ylim=(-4.0, 4.0), extrap={'left': 'linear', 'right': 'linear'})
+    cpl = (AffineCoupling_([net, net], mask=mask) if kind == 'affine' else RQSplineCoupling_([net, net], mask=mask, **lim)).to(DEV)
+    x = 1.3 * torch.randn((B,) + shape, device=DEV, dtype=torch.float32)
+    convs = [mod for mod in net if hasattr(mod, 'weight')]
+    layers = [(c.weight.detach().double().cpu(), c.bias.detach().double().cpu()) for c in convs]
+    nb = min(B, 8)
+    opts = None if kind == 'affine' else _hip.make_rqs_opts(m, lim["xlim"], lim["ylim"], lim["extrap"], _hip.LAYOUT_PAIR)
+    for parity in (0, 1):
+        xa, xf = mask.purify(x, parity), mask.purify(x, 1 - parity)
+        l0 = torch.randn(B, device=DEV, dtype=torch.float32)
+        with torch.no_grad():
+            got = cpl._small_lattice_atom(1 if kind == 'affine' else 0, False, xa, xf, parity, net, l0, opts)
+            assert got is not None, "the small-lattice fused kernel did not take this layer"
+            yf, lf = got
+            yv, lv = cpl.atomic_forward(x_active=xa, x_frozen=xf, parity=parity, net=net, log0=l0)
+            assert torch.equal(yv, yf) and torch.equal(lv, lf)
+            with _hip.options(split16=False):
+                yu, lu = cpl.atomic_forward(x_active=xa, x_frozen=xf, parity=parity, net=net, log0=l0)
+            assert rel(yf, yu) <= 1e-5 and rel(lf, lu) <= 1e-5, (rel(yf, yu), rel(lf, lu))
+            perm = torch.randperm(B, device=DEV)
+            yp, lp = cpl.atomic_forward(x_active=xa[perm], x_frozen=xf[perm], parity=parity, net=net, log0=l0[perm])
+            assert torch.equal(yp, yf[perm]) and torch.equal(lp, lf[perm])
+            xb, lb = cpl.atomic_backward(x_active=yf, x_frozen=xf, parity=parity, net=net, log0=lf)
+        am = O.channel_mask(shape, parity)
+        assert float((yf.double().cpu() * (1 - am)).abs().max()) == 0.0
+        out = O.conv_act(xf[:nb].double().cpu().unsqueeze(1), layers, acts)
+        atom = O.affine_coupling_atom if kind == 'affine' else O.rqs_coupling_atom
+        kw = {} if kind == 'affine' else lim
+        yo, lo = atom(xa[:nb].double().cpu(), out, am, log0=l0[:nb].double().cpu(), **kw)
+        ey, el = rel(yf[:nb], yo), rel(lf[:nb], lo)
+        parity_report(f"small lattice {kind} {shape} h={hidden} p{parity}", "y / logJ vs fp64 oracle", max(ey, el), 1e-5)
+        assert ey <= 1e-5 and el <= 1e-5, (ey, el)
+        if kind == 'affine':        # x = (y - t) e^{|s|}: conditioned by e^{|s|} <= e^2 here
+            assert rel(xb, xa) <= 2e-5 and rel(lb, l0) <= 2e-5, (rel(xb, xa), rel(lb, l0))
+        else:
+            with torch.no_grad():
+                y2, _ = cpl.atomic_forward(x_active=xb, x_frozen=xf, parity=parity, net=net, log0=l0)
+            assert rel(y2, yf) <= 2e-5
