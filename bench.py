@@ -53,6 +53,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-products", action="store_true", help="skip the exact-fp32-product leg")
     ap.add_argument("--no-selfcheck", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short timings of BASELINE configs 2, 3 and 5")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU baseline sample")
     ap.add_argument("--kernel-reps", type=int, default=10)
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of a self-launched run (0 = pick a free one)")
@@ -326,6 +327,54 @@ def cpu_baseline(cpl, lattice, m, budget_s):
                        f"timed repetitions, median, extrapolated linearly to {n_layers} layers; {time.time() - t_start:.1f} s of CPU work")
 
 
+# ------------------------------------------------------------------------------------------ the other BASELINE configurations
+def other_configs(dev):
+    """Short timings of BASELINE.json's other GPU configurations (parity-test cases, NOT the bench metric: reported as extra
+    fields so that the driver's own run shows them): config 2 (16x16, 4 affine layers, batch 512), config 3 (16^3, 8 RQ-spline
+    layers m=16, batch 1024) -- both on the small-lattice fused kernel, one launch per layer --, and config 5's lattice and
+    precision (48^4, 8 affine + 8 spline layers, fp16 parameters and field, fp32 log-det) at batch 8.  Forward + log|det J|,
+    no_grad, synthetic inputs, one net per block, each: 1 warm-up + `reps` timed passes between synchronisations."""
+    import torch
+    from normflow__amd.nn import ConvAct, RQSplineCoupling_, AffineCoupling_, ModuleList_
+    from normflow__amd.mask import EvenOddMask
+
+    def build(shape, kinds, dtype):
+        d = len(shape)
+        mask = EvenOddMask(shape=shape)
+        lim = dict(xlim=(-5.0, 5.0), ylim=(-5.0, 5.0), extrap={'left': 'linear', 'right': 'linear'})
+        blocks = []
+        for kind in kinds:
+            net = ConvAct(1, 46 if kind == 'rqs' else 2, 3, conv_dim=d, hidden_sizes=[8, 8], acts=['tanh', 'tanh', None])
+            with torch.no_grad():
+                for p in list(net.parameters())[-2:]:
+                    p.mul_(0.3)
+            blocks.append(RQSplineCoupling_([net], mask=mask, **lim) if kind == 'rqs' else AffineCoupling_([net], mask=mask))
+        net_ = ModuleList_(blocks)
+        net_.to(device=dev, dtype=dtype)
+        return net_
+
+    out = {}
+    for name, shape, kinds, B, dtype, reps in (
+            ("config2_16x16_4affine_b512", (16, 16), ['affine'] * 4, 512, torch.float32, 20),
+            ("config3_16x16x16_8rqs_b1024", (16, 16, 16), ['rqs'] * 8, 1024, torch.float32, 10),
+            ("config5_48x48x48x48_8affine8rqs_fp16storage_b8", (48,) * 4, ['affine', 'rqs'] * 8, 8, torch.float16, 2)):
+        torch.manual_seed(0)
+        net_ = build(shape, kinds, dtype)
+        x = torch.randn((B,) + shape, device=dev, dtype=torch.float32).to(dtype)
+        with torch.no_grad():
+            y, lj = net_(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                y, lj = net_(x)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        assert bool(torch.isfinite(lj).all()) and bool(torch.isfinite(y.float()).all())
+        out[name] = {"configs_per_s": B / dt, "ms_per_step": 1e3 * dt, "batch": B, "layers": len(kinds)}
+        del net_, x, y, lj
+    return out
+
+
 # ------------------------------------------------------------------------------------------ main
 def main():
     a = parse()
@@ -506,6 +555,8 @@ def main():
             line["fp32_products"] = dict(fp32_leg, arithmetic="exact fp32 MFMA products everywhere (nf_set_option(NF_OPT_SPLIT16, 0)); same network, same input")
         if selfcheck is not None:
             line["selfcheck"] = selfcheck
+        if not a.no_other_configs and world == 1:
+            line["other_configs"] = other_configs(dev)
         if not a.no_cpu_baseline and world == 1:     # CPU baseline: rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(cpl, lattice, a.knots, a.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -9,7 +9,7 @@ P=gpurun_out/${TAG}p
 mkdir -p $P
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python bench.py --steps 3 --warmup 1 > $P/bench.json 2> $P/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $P/bench_under_rocprof.json 2> $P/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs > $P/bench_under_rocprof.json 2> $P/trace.err
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $P/$c -o run -- python3 tools/kbench.py --reps 2 > $P/$c.log 2>&1
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $P/${c}_k2 -o run -- python3 tools/kbench.py --only k2 --reps 3 > $P/${c}_k2.log 2>&1
@@ -18,7 +18,7 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_
 for f in $P/FETCH_SIZE_k2/*/*counter_collection.csv $P/FETCH_SIZE_k2/*counter_collection.csv; do [ -f "$f" ] && cp $f $P/FETCH_SIZE/k2_counter_collection.csv; done
 for f in $P/WRITE_SIZE_k2/*/*counter_collection.csv $P/WRITE_SIZE_k2/*counter_collection.csv; do [ -f "$f" ] && cp $f $P/WRITE_SIZE/k2_counter_collection.csv; done
 python tools/make_pmc_profile.py --fetch $P/FETCH_SIZE --write $P/WRITE_SIZE --sq $P/sq --out $P/pmc_kernels.json --note "round 3 kernels (conv_c2 / conv_g2 / conv_h as round 2 + run-time knots_len in conv_h); kbench at the pipeline's 256-sample slab; K2 at its 33-sample slab"
-python bench.py --steps 3 --warmup 1 --batch 128 --no-cpu-baseline > $P/bench_batch128.json 2> $P/bench128.err || true
+python bench.py --steps 3 --warmup 1 --batch 128 --no-cpu-baseline --no-other-configs > $P/bench_batch128.json 2> $P/bench128.err || true
 python tools/config_bench.py > $P/config_bench.txt 2>&1 || true
 python tools/c3_bench.py > $P/c3_bench.txt 2>&1 || true
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/c3trace -o run -- python3 tools/c3_prof.py > $P/c3trace.log 2>&1 || true

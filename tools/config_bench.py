@@ -46,8 +46,29 @@ def run(name, shape, kinds, B, reps=3, dtype=torch.float32, m=16, hidden=8):
     print(f"{name:34s} B={B:5d}  {dt * 1e3:9.2f} ms/step  {B / dt:10.1f} configs/s  {sites * len(kinds) / dt / 1e9:7.2f} Gsite-layers/s")
 
 
+def run_graphed(name, shape, kinds, B, reps=50):
+    """The same pass replayed from a HIP graph (normflow__amd.GraphedFlow): what is left when the host's launch path is gone."""
+    from normflow__amd import GraphedFlow
+    torch.manual_seed(0)
+    net = build(shape, kinds)
+    x = torch.randn((B,) + shape, device=DEV, dtype=torch.float32)
+    g = GraphedFlow(net, x)
+    g(x, clone=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g(x, clone=False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    sites = B
+    for n in shape:
+        sites *= n
+    print(f"{name:34s} B={B:5d}  {dt * 1e3:9.2f} ms/step  {B / dt:10.1f} configs/s  {sites * len(kinds) / dt / 1e9:7.2f} Gsite-layers/s")
+
+
 if __name__ == "__main__":
     run("c2 16x16, 4 affine", (16, 16), ['affine'] * 4, 512, reps=20)
+    run_graphed("c2 16x16, 4 affine (HIP graph)", (16, 16), ['affine'] * 4, 512)
     run("c3 16^3, 8 rqs m=16", (16, 16, 16), ['rqs'] * 8, 1024)
     run("c4 32^4, 8 rqs (per-GPU share)", (32,) * 4, ['rqs'] * 8, 128)
     run("c5 48^4, 8 affine + 8 rqs", (48,) * 4, ['affine', 'rqs'] * 8, 8)
