@@ -88,8 +88,11 @@ const char *nf_last_error_string(void);
  *                  (nf_conv_weight_layout / nf_conv_split16_supported answer accordingly);
  *   NF_OPT_PIPE    (default 1): eligible fp32 layers run the persistent, staging-overlapped kernels (nf_conv_pipe.hip);
  *                  0 = one box per workgroup (nf_conv.hip).
- * nf_set_option returns the previous value (>= 0) or NF_EINVAL; set options before launching, not concurrently with calls. */
-enum nf_option { NF_OPT_SPLIT16 = 0, NF_OPT_PIPE = 1, NF_OPT_COUNT_ = 2 };
+ *   NF_OPT_SMALL8  (default 1): the small-lattice fused layer (nf_small3d_rqs / nf_small_lattice_coupling) runs its
+ *                  eight-wave form (two roles, two waves per SIMD); 0: the four-wave form (every wave holds all weights).
+ * nf_set_option returns the previous value (>= 0) or NF_EINVAL; set options before launching, not concurrently with calls.
+ */
+enum nf_option { NF_OPT_SPLIT16 = 0, NF_OPT_PIPE = 1, NF_OPT_SMALL8 = 2, NF_OPT_COUNT_ = 3 };
 int nf_set_option(int which, int value);
 int nf_get_option(int which);
 

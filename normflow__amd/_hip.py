@@ -20,7 +20,7 @@ LAYOUT_FULL, LAYOUT_PAIR = 0, 1
 EXTRAP = {None: 0, 'none': 0, 'linear': 1, 'anti': 2, 'anti-periodic': 2}
 
 
-OPT_SPLIT16, OPT_PIPE = 0, 1
+OPT_SPLIT16, OPT_PIPE, OPT_SMALL8 = 0, 1, 2
 
 
 class NormflowHipError(RuntimeError):
@@ -134,7 +134,7 @@ def load():
 class options:
     """Context manager / setter for the library's kernel-selection options (include/normflow_hip.h, nf_set_option):
     `with _hip.options(split16=False): ...` runs the block with exact fp32 MFMA products everywhere."""
-    _CODES = {"split16": OPT_SPLIT16, "pipe": OPT_PIPE}
+    _CODES = {"split16": OPT_SPLIT16, "pipe": OPT_PIPE, "small8": OPT_SMALL8}
 
     def __init__(self, **kw):
         self._new = {self._CODES[k]: int(bool(v)) for k, v in kw.items()}

@@ -9,7 +9,7 @@ static thread_local char g_err[512] = "";
 
 // ---- process-wide kernel-selection options (nf_set_option / nf_get_option).  Plain ints written by the host thread that
 // configures the library; kernels never read them, only the launch planners do.
-static int g_options[NF_OPT_COUNT_] = {1, 1};
+static int g_options[NF_OPT_COUNT_] = {1, 1, 1};
 int option(int which) { return (which >= 0 && which < NF_OPT_COUNT_) ? g_options[which] : 0; }
 
 void set_error(const char *fmt, ...) {

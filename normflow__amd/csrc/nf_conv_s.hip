@@ -327,6 +327,282 @@ __global__ __launch_bounds__(256, 1) void conv_small3d_kernel(SmallArgs A) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same layer with EIGHT waves in two roles, two waves per SIMD (K5s above holds all weights in every wave: ~420 registers,
+// one wave per SIMD, and its counters say it is bound by vector issue and latency, not by the matrix pipe: a wave's
+// dependent chains have nothing to hide behind).  Waves 0-3 ("AB"): stages A and B and the spline passes -- vector-heavy,
+// 80 weight registers; waves 4-7 ("C"): the last layer's 63 MFMAs per tile -- matrix-heavy, 168 weight registers.  Wave w
+// and wave w + 4 own the same tiles and share the logit scratch: C(t) writes half t & 1 of it between barriers, the AB wave
+// maps those sites one interval later.  Interval t (two barriers, as before):
+//     AB:  spline(t-1), request the field values of plane t, A(t+3) | bar | B(t+2)              | bar
+//     C :  first tile of C(t)                                       | bar | second tile of C(t) | bar
+// Ring hazards: C(t) reads H2[t-1 .. t+1] while B(t+2) writes slot t+2 = t-2 (mod 4); A(t+3) writes H1 slot t-1, last read by
+// B(t) one interval earlier.  (Tried: stage A moved to the C waves and run one interval ahead, two rows per phase -- the C
+// waves then need 256 registers + 60 bytes of scratch and the kernel is 10 % slower: 3.33 against 3.02 ms per config-3 step.)
+template <bool INV, int KIND>
+__global__ __launch_bounds__(512, 1) void conv_small3d_kernel8(SmallArgs A) {
+  using namespace s3;
+  extern __shared__ __align__(16) unsigned char smem_s[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int role = wave >> 2, w4 = wave & 3;
+  const int g = lane >> 4, n = lane & 15;
+  const int L0 = A.L0, L1 = A.L1;
+  const int V = L0 * L1 * LX, PSITES = L1 * LX;
+  const int PB = PSITES * 32, HL = PSITES * 16;
+  const int PY = L1 + 2;
+  const int XB = int(x_bytes(L0, L1));
+  unsigned char *Xh = smem_s, *Xl = smem_s + XB;
+  unsigned char *H1 = smem_s + 2 * XB;
+  unsigned char *H2 = H1 + RING * PB;
+  float *pt = reinterpret_cast<float *>(H2 + RING * PB) + w4 * (48 * PTS);
+  double *red = reinterpret_cast<double *>(H2 + RING * PB + 4 * PTW);
+  constexpr int NT = KIND == 1 ? 1 : 3;
+  const int ntw = (L1 / 2 - w4 + 3) / 4;
+  auto wrap1 = [](int v, int L) { return v < 0 ? v + L : (v >= L ? v - L : v); };
+  auto ring = [&](int p) { return ((p + 8) & (RING - 1)) * PB; };
+  const bool flat = A.flat != 0;
+  const int t0 = flat ? -3 : -5;
+  auto a_valid = [&](int p) { return flat ? p == 0 : (p >= -2 && p <= L0 + 1); };
+  auto b_valid = [&](int p) { return flat ? p == 0 : (p >= -1 && p <= L0); };
+
+  if (flat) {
+    for (int i = threadIdx.x * 16; i < 2 * RING * PB; i += 512 * 16) *reinterpret_cast<f32x4 *>(H1 + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  auto load_x = [&](int64_t sbase) {
+    for (int i = threadIdx.x; i < (L0 + 2) * PY * PX; i += 512) {
+      const int hz = i / (PY * PX), rem = i - hz * (PY * PX), hy = rem / PX, hx = rem - hy * PX;
+      const int sz = wrap1(hz - 1, L0), sy = wrap1(hy - 1, L1), sx = (hx - 1) & (LX - 1);
+      const float v = A.xf[sbase + (sz * L1 + sy) * LX + sx];
+      const _Float16 hi = static_cast<_Float16>(v);
+      reinterpret_cast<_Float16 *>(Xh)[i] = hi;
+      reinterpret_cast<_Float16 *>(Xl)[i] = static_cast<_Float16>(v - static_cast<float>(hi));
+    }
+  };
+
+  if (role == 0) {
+    // ================================================================================ waves 0-3: stages A, B and the spline
+    const f16x8 a1h = A.w1[lane], a1l = A.w1[64 + lane];
+    f16x8 a2h[9], a2l[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      a2h[r] = A.w2[(2 * r) * 64 + lane];
+      a2l[r] = A.w2[(2 * r + 1) * 64 + lane];
+    }
+    const float be1 = A.act1 == kActTanh ? 2.f : 1.f, be2 = A.act2 == kActTanh ? 2.f : 1.f;
+    const float al1 = be1, ga1 = 1.f - be1, al2 = be2, ga2 = 1.f - be2;
+    const float c11 = -be1 * Num<float>::kLog2e * kInvWScale, c12 = -be2 * Num<float>::kLog2e * kInvWScale;
+    float c01[4], c02[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      c01[r] = -be1 * Num<float>::kLog2e * ((A.b1 && g < 2) ? A.b1[4 * g + r] : 0.f);
+      c02[r] = -be2 * Num<float>::kLog2e * (A.b2 ? A.b2[4 * (g & 1) + r] : 0.f);
+    }
+    auto act_of = [](float acc, float c1, float c0, float al, float ga) {
+      const float t = Num<float>::exp2(__builtin_fmaf(acc, c1, c0));
+      return __builtin_fmaf(al, __builtin_amdgcn_rcpf(1.f + t), ga);
+    };
+    int tapA[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = 8 * g + i;
+      tapA[i] = k < 27 ? (((k / 9 - 1) * PY + ((k / 3) % 3 - 1)) * PX + (k % 3 - 1)) * 2 : 0;
+    }
+    auto stageA = [&](int p) {
+      int pz = p % L0;
+      pz = pz < 0 ? pz + L0 : pz;
+      unsigned char *dst = H1 + ring(p);
+      for (int T = w4; T < L1 / 2; T += 4) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const int yrow = 2 * T + rr;
+          f16x8 xh, xl;
+          const int ctr = (((pz + 1) * PY + yrow + 1) * PX + n + 1) * 2;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            xh[i] = *reinterpret_cast<const _Float16 *>(Xh + ctr + tapA[i]);
+            xl[i] = *reinterpret_cast<const _Float16 *>(Xl + ctr + tapA[i]);
+          }
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, xh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, xl, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l, xh, acc, 0, 0, 0);
+          if (g < 2) {
+            f16x4 hi, lo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float v = act_of(acc[r], c11, c01[r], al1, ga1);
+              hi[r] = static_cast<_Float16>(v);
+              lo[r] = static_cast<_Float16>(v - static_cast<float>(hi[r]));
+            }
+            unsigned char *d = dst + (yrow * LX + n) * 16 + g * 8;
+            *reinterpret_cast<f16x4 *>(d) = hi;
+            *reinterpret_cast<f16x4 *>(d + HL) = lo;
+          }
+        }
+      }
+    };
+    auto stageB = [&](int p) {
+      unsigned char *dst = H2 + ring(p);
+      const int rr = n >> 3, q = n & 7;
+      const int xs = (2 * q + g - 1) & (LX - 1);
+      for (int T = w4; T < L1 / 2; T += 4) {
+        const int yrow = 2 * T + rr;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j0 = 0; j0 < 3; ++j0) {
+          const unsigned char *pl = H1 + ring(p + j0 - 1);
+#pragma unroll
+          for (int j1 = 0; j1 < 3; ++j1) {
+            const int yr = wrap1(yrow + j1 - 1, L1);
+            const unsigned char *src = pl + (yr * LX + xs) * 16;
+            const f16x8 fh = *reinterpret_cast<const f16x8 *>(src);
+            const f16x8 fl = *reinterpret_cast<const f16x8 *>(src + HL);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2h[3 * j0 + j1], fh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2h[3 * j0 + j1], fl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2l[3 * j0 + j1], fh, acc, 0, 0, 0);
+          }
+        }
+        f16x4 hi, lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = act_of(acc[r], c12, c02[r], al2, ga2);
+          hi[r] = static_cast<_Float16>(v);
+          lo[r] = static_cast<_Float16>(v - static_cast<float>(hi[r]));
+        }
+        unsigned char *d = dst + (yrow * LX + 2 * q + (g >> 1)) * 16 + (g & 1) * 8;
+        *reinterpret_cast<f16x4 *>(d) = hi;
+        *reinterpret_cast<f16x4 *>(d + HL) = lo;
+      }
+    };
+    double lacc = 0.0;
+    float xpre = 0.f;
+    int64_t spre = -1;
+    auto prefetch_x = [&](int z, int64_t sbase) {       // the field values of plane z's sites (this wave's tiles), one interval ahead
+      spre = -1;
+      const int u = lane;
+      if (z >= 0 && z < L0 && u < ntw * 16) {
+        const int T = w4 + 4 * (u >> 4), m_ = u & 15;
+        const int yrow = 2 * T + (m_ >> 3), qq = m_ & 7;
+        const int xsite = 2 * qq + ((A.parity + z + yrow) & 1);
+        spre = sbase + (int64_t(z) * L1 + yrow) * LX + xsite;
+        xpre = A.xa[spre];
+      }
+    };
+    auto spline = [&](int z) {                          // plane z's logits: half z & 1 of the shared scratch, written by wave w4 + 4
+      if (spre >= 0) {
+        const int u = (z & 1) * 32 + lane;
+        float val, logd;
+        if constexpr (KIND == 1) {
+          const float tt = pt[u], ss = fabsf(pt[PTS + u]);
+          val = INV ? (xpre - tt) * __expf(ss) : tt + xpre * __expf(-ss);
+          logd = INV ? ss : -ss;
+        } else if (A.P.m == M) {
+          RegCol<float, C> col;
+#pragma unroll
+          for (int c = 0; c < C; ++c) col[c] = pt[c * PTS + u];
+          rqs_site<float, M, INV>(col, A.P, xpre, val, logd);
+        } else {
+          LdsCol<float> col{pt + u, PTS};
+          rqs_site<float, 0, INV>(col, A.P, xpre, val, logd);
+        }
+        A.y[spre] = val;
+        A.y[spre ^ 1] = 0.f;
+        lacc += double(logd);
+      }
+    };
+    for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
+      const int64_t sbase = b * int64_t(V);
+      load_x(sbase);
+      lacc = 0.0;
+      spre = -1;
+      lds_barrier();
+      for (int t = t0; t <= L0; ++t) {
+        if (t >= 1) spline(t - 1);
+        prefetch_x(t, sbase);
+        if (a_valid(t + 3)) stageA(t + 3);
+        lds_barrier();
+        if (b_valid(t + 2)) stageB(t + 2);
+        lds_barrier();
+      }
+      const double tot = wave_sum(lacc);
+      if (lane == 0) red[w4] = tot;
+      lds_barrier();
+      if (threadIdx.x == 0) A.logj[b] = float((A.log0 ? double(A.log0[b]) : 0.0) + ((red[0] + red[1]) + (red[2] + red[3])));
+      lds_barrier();
+    }
+    return;
+  }
+
+  // ================================================================================== waves 4-7: the last layer's logits
+  f16x8 b3h[7][NT], b3l[7][NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      b3h[i][t] = A.w3[((t * 7 + i) * 2) * 64 + lane];
+      b3l[i][t] = A.w3[((t * 7 + i) * 2 + 1) * 64 + lane];
+    }
+  float b3v[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) b3v[t] = (A.b3 && 16 * t + n < A.cout) ? A.b3[16 * t + n] : 0.f;
+  int tapC[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int k = 4 * i + g;
+    tapC[i] = k < 27 ? (k / 9) | (((k / 3) % 3) << 2) | ((k % 3) << 4) : (1 | (1 << 2) | (1 << 4));
+  }
+  auto logits_tile = [&](int z, int nt) {               // tile nt (0, 1) of this wave in plane z
+    const int T = w4 + 4 * nt;
+    if (T >= L1 / 2) return;
+    const int rr = n >> 3, q = n & 7;
+    const int yrow = 2 * T + rr;
+    const int xa = 2 * q + ((A.parity + z + yrow) & 1);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int yr = wrap1(yrow + ((tapC[i] >> 2) & 3) - 1, L1);
+      const int xr = (xa + ((tapC[i] >> 4) & 3) - 1) & (LX - 1);
+      const unsigned char *src = H2 + ring(z + (tapC[i] & 3) - 1) + (yr * LX + xr) * 16;
+      const f16x8 fh = *reinterpret_cast<const f16x8 *>(src);
+      const f16x8 fl = *reinterpret_cast<const f16x8 *>(src + HL);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, b3h[i][t], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, b3h[i][t], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, b3l[i][t], acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int ch = 16 * t + n;
+      if (ch < A.cout) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[t][r] * kInvWScale + b3v[t];
+        *reinterpret_cast<f32x4 *>(pt + ch * PTS + (z & 1) * 32 + nt * 16 + 4 * g) = v;
+      }
+    }
+  };
+  for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
+    const int64_t sbase = b * int64_t(V);
+    load_x(sbase);
+    lds_barrier();
+    for (int t = t0; t <= L0; ++t) {
+      const bool on = t >= 0 && t < L0;
+      if (on) logits_tile(t, 0);
+      lds_barrier();
+      if (on) logits_tile(t, 1);
+      lds_barrier();
+    }
+    lds_barrier();
+    lds_barrier();
+  }
+}
+
 }  // namespace nf
 
 using namespace nf;
@@ -387,14 +663,19 @@ static int small_launch(const char *who, int kind, const void *x_frozen, const v
   }
   const int64_t grid = B < ncu ? B : ncu;
   const int lds = int(s3::lds_bytes(A.L0, A.L1));
-  auto go = [&](auto kern) {
+  auto go = [&](auto kern, int threads) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -1;
-    hipLaunchKernelGGL(kern, dim3(unsigned(grid)), dim3(256), lds, stream, A);
+    hipLaunchKernelGGL(kern, dim3(unsigned(grid)), dim3(threads), lds, stream, A);
     return 0;
   };
   int rc;
-  if (kind == 0) rc = inverse ? go(&conv_small3d_kernel<true, 0>) : go(&conv_small3d_kernel<false, 0>);
-  else rc = inverse ? go(&conv_small3d_kernel<true, 1>) : go(&conv_small3d_kernel<false, 1>);
+  if (option(NF_OPT_SMALL8)) {       // eight waves in two roles (the default)
+    if (kind == 0) rc = inverse ? go(&conv_small3d_kernel8<true, 0>, 512) : go(&conv_small3d_kernel8<false, 0>, 512);
+    else rc = inverse ? go(&conv_small3d_kernel8<true, 1>, 512) : go(&conv_small3d_kernel8<false, 1>, 512);
+  } else {
+    if (kind == 0) rc = inverse ? go(&conv_small3d_kernel<true, 0>, 256) : go(&conv_small3d_kernel<false, 0>, 256);
+    else rc = inverse ? go(&conv_small3d_kernel<true, 1>, 256) : go(&conv_small3d_kernel<false, 1>, 256);
+  }
   if (rc != 0) {
     set_error("%s: could not configure the kernel's LDS (%d bytes)", who, lds);
     return NF_ELAUNCH;

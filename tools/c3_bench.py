@@ -10,5 +10,7 @@ if __name__ == "__main__":
     cb.run("c3 16^3, 8 rqs m=16 (K5s)", (16, 16, 16), ["rqs"] * 8, 1024, reps=10)
     cb.run("c3 16^3, 8 rqs m=16 (K5s)", (16, 16, 16), ["rqs"] * 8, 4096, reps=5)
     cb.run("c3 16^3, 8 rqs m=8  (K5s)", (16, 16, 16), ["rqs"] * 8, 1024, reps=10, m=8)
+    with _hip.options(small8=False):
+        cb.run("c3 16^3, m=16 (K5s, 4-wave form)", (16, 16, 16), ["rqs"] * 8, 1024, reps=10)
     with _hip.options(split16=False):
         cb.run("c3 16^3, fp32 kernels", (16, 16, 16), ["rqs"] * 8, 1024, reps=5)
