@@ -676,7 +676,7 @@ def pack_conv_weight_split16_first(w):
     return out.contiguous()
 
 
-def conv_first_split16(x, weight, bias, act):
+def conv_first_split16(x, weight, bias, act, weight_src=None):
     """First ConvAct layer 1 -> 8 on the split-fp16 kernel (nf_conv_first_split16): x (B, 1, *L) fp32 -> the fp16 pair
     tensor (B, V, 16); inference only."""
     lib = load()
@@ -686,7 +686,7 @@ def conv_first_split16(x, weight, bias, act):
     V = 1
     for n in lat:
         V *= n
-    wsp = pack_conv_weight_split16_first(weight.detach())
+    wsp = _cached_pack(weight if weight_src is None else weight_src, 'first16', pack_conv_weight_split16_first)
     bias = None if bias is None else bias.detach().float().contiguous()
     out = torch.empty((B, V, 16), dtype=torch.float16, device=x.device)
     step = max(1, min(MAX_B, ((1 << 31) - 1) // V))
@@ -738,7 +738,7 @@ def conv_layer_split16(h16, weight, bias, act, lattice):
     lib = load()
     B = h16.shape[0]
     lat4 = (C.c_int32 * 4)(*lattice)
-    wsp = pack_conv_weight_split16_two_site(weight.detach())
+    wsp = _cached_pack(weight, 'two_site16', pack_conv_weight_split16_two_site)
     bias = None if bias is None else bias.detach().float().contiguous()
     out = torch.empty_like(h16)
     for b0 in range(0, B, MAX_B):
@@ -752,9 +752,29 @@ _UNIT_OK = {}
 
 
 def invalidate_weight_checks():
-    """Forget every cached verdict of `_weights_fit_fp16` (call after editing weights through `.data`, which does not
-    bump a tensor's version counter)."""
+    """Forget every cached verdict of `_weights_fit_fp16` and every cached fragment packing (call after editing weights
+    through `.data`, which does not bump a tensor's version counter)."""
     _UNIT_OK.clear()
+    _PACKED.clear()
+
+
+_PACKED = {}
+
+
+def _cached_pack(w, kind, fn):
+    """fn(w.detach()) -- a weight tensor repacked into a kernel's fragment layout -- cached per live tensor OBJECT (the
+    parameter a view like Conv4d.weight is based on, held by weak reference as in `_weights_fit_fp16`) and version, so that
+    an inference pass does not repack (a dozen small torch kernels per layer and launch) weights that have not changed.
+    A detached alias or a temporary has no live base: it is packed every time."""
+    base = w._base if w._base is not None else w
+    key = (id(base), kind)
+    state = (w._version, w.data_ptr(), tuple(w.shape), w.dtype)
+    hit = _PACKED.get(key)
+    if hit is not None and hit[0]() is base and hit[1] == state:
+        return hit[2]
+    out = fn(w.detach())
+    _PACKED[key] = (weakref.ref(base, lambda _, k=key: _PACKED.pop(k, None)), state, out)
+    return out
 
 
 def _weights_fit_fp16(w):
@@ -799,7 +819,7 @@ def _conv_launch(x, weight, bias, act, compact, parity, weight_src=None):
     if (split16 and cin == 1 and cout == 8 and d == 4 and x.dtype == torch.float32
             and _weights_fit_fp16(weight if weight_src is None else weight_src)     # (the caller's tensor: its verdict is cached)
             and lib.nf_conv_first_split16_supported(lat4, k4, cout, act)):
-        return conv_first_split16(x, weight, bias, act)
+        return conv_first_split16(x, weight, bias, act, weight_src)
     if split16 and not (lib.nf_conv_two_site(cout, 0, lat[-1], ksize[-1]) and cout == 8 and x.dtype == torch.float32):
         raise NormflowHipError("split-fp16 output needs an fp32 two-site layer with 8 output channels")
     if lib.nf_conv_two_site(cout, 0 if split16 else int(compact), lat[-1], ksize[-1]):
@@ -1147,9 +1167,11 @@ def conv_affine_split16(h16, weight, bias, x_active, log0, parity, inverse, latt
     B, V = x_active.shape
     x_active = x_active.contiguous()
     lat4 = (C.c_int32 * 4)(*lattice)
-    w8 = weight.new_zeros((8, 8, 3, 3, 3, 3), dtype=torch.float32)
-    w8[:2] = weight.detach().float()
-    wsp = pack_conv_weight_split16_two_site(w8)
+    def pack_affine(w):
+        w8 = w.new_zeros((8, 8, 3, 3, 3, 3), dtype=torch.float32)
+        w8[:2] = w.float()
+        return pack_conv_weight_split16_two_site(w8)
+    wsp = _cached_pack(weight, 'affine16', pack_affine)
     b8 = torch.zeros(8, dtype=torch.float32, device=x_active.device)
     if bias is not None:
         b8[:2] = bias.detach().float()
@@ -1194,7 +1216,9 @@ def conv_rqs(h, weight, bias, x_active, log0, parity, opts, inverse, unit_input=
         if not flags or h.dtype != torch.float16 or tuple(h.shape) != (B, V, 16):
             raise NormflowHipError("split-fp16 hidden activations need unit_input and a (B, V, 16) half tensor")
         flags |= 2                                                           # NF_CONV_SPLIT16_INPUT
-    wfrag = conv_weight_for_layer(weight.detach(), lat4, k4, cin, weight.shape[0], True, 1 | ((flags & 1) << 1) | ((flags & 2) << 1), NF_F32)
+    fused_code = 1 | ((flags & 1) << 1) | ((flags & 2) << 1)
+    kind = ('fused_last', tuple(lat4), tuple(k4), cin, fused_code, lib.nf_get_option(OPT_SPLIT16), lib.nf_get_option(OPT_PIPE))
+    wfrag = _cached_pack(weight, kind, lambda w: conv_weight_for_layer(w, lat4, k4, cin, w.shape[0], True, fused_code, NF_F32))
     bias = None if bias is None else bias.detach().contiguous()
     if out is None:
         y = torch.empty_like(x_active)
