@@ -2288,3 +2288,41 @@ def test_small_lattice_affine_and_2d_vs_oracle(shape, B, kind, m, hidden, parity
             with torch.no_grad():
                 y2, _ = cpl.atomic_forward(x_active=xb, x_frozen=xf, parity=parity, net=net, log0=l0)
             assert rel(y2, yf) <= 2e-5
+
+
+from test_oracle_golden import small16_cases, SMALL16_LIM
+
+
+@pytest.mark.parametrize("tag", small16_cases())
+def test_small_lattice_kernel_against_reference_goldens(golden, tag, parity_report):
+    """nf_conv_s.hip against the REFERENCE itself (tests/golden/small16.npz, written by make_golden_small16.py from the imported
+    reference): whole Coupling_ blocks with the reference's weights (same state_dict keys) on 2-D / 3-D lattices with a 16-site
+    fastest axis -- BASELINE config 2's 16 x 16 affine block and config 3's net on 4 x 6 x 16 among them.  fp32, no_grad (the
+    fused path), forward and inverse: north_star's 1e-5 on y and log|J|."""
+    z = golden("small16")
+    kind = tag.split("/")[0]
+    shape = tuple(int(v) for v in z[f"{tag}/shape"])
+    m, hidden, d = int(z[f"{tag}/m"]), int(z[f"{tag}/hidden"]), len(shape)
+    n_out = 2 if kind == "affine" else 3 * m - 2
+    nets = [ConvAct(1, n_out, 3, conv_dim=d, hidden_sizes=[hidden, hidden], acts=['tanh', 'tanh', None]) for _ in range(2)]
+    mask = EvenOddMask(shape=shape)
+    cpl = AffineCoupling_(nets, mask=mask) if kind == "affine" else RQSplineCoupling_(nets, mask=mask, **SMALL16_LIM)
+    sd = {k.split("/param/")[1]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"{tag}/param/")}
+    missing, unexpected = cpl.load_state_dict(sd, strict=False)
+    assert not unexpected and set(missing) == {"mask._mask", "mask._c_mask"}
+    cpl = cpl.to(device=DEV, dtype=torch.float32)
+    x = T(z[f"{tag}/x"], torch.float32)
+    with torch.no_grad():
+        xa, xf = mask.purify(x, 0), mask.purify(x, 1)
+        so = None if kind == "affine" else _hip.make_rqs_opts(m, (-3.0, 3.0), (-3.0, 3.0), SMALL16_LIM["extrap"], _hip.LAYOUT_PAIR)
+        took = cpl._small_lattice_atom(1 if kind == "affine" else 0, False, xa, xf, 0, cpl.nets[0], 0, so)
+        assert took is not None, "the small-lattice fused kernel did not take this block"
+        y, logJ = cpl(x)
+        xh, lrt = cpl.backward(T(z[f"{tag}/y"], torch.float32), T(z[f"{tag}/logJ"], torch.float32))
+        y2, _ = cpl(xh)
+    ey, el = rel(y, z[f"{tag}/y"]), rel(logJ, z[f"{tag}/logJ"])
+    parity_report(f"small16 {tag}", "y / logJ vs the reference", max(ey, el), 1e-5)
+    assert ey <= 1e-5 and el <= 1e-5, (ey, el)
+    assert rel(y2, z[f"{tag}/y"]) <= 2e-5                      # the inverse, through its forward residual
+    if kind == "affine":
+        assert rel(xh, z[f"{tag}/x"]) <= 2e-5 and float(lrt.abs().max()) <= 2e-5 * max(1.0, float(np.abs(z[f"{tag}/logJ"]).max()))

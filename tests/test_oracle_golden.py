@@ -245,3 +245,37 @@ def test_philox_known_answers_and_prior_sampler_oracle():
     assert float((x.mean(dim=0) - loc).abs().max()) < 0.05 and float((x.std(dim=0) / scale - 1).abs().max()) < 0.03
     ref = torch.distributions.Normal(loc.double(), scale.double()).log_prob(x).sum(dim=1)
     close(logr, ref, 1e-12)
+
+
+# ------------------------------------------------------------------ small 16-wide lattices (the shapes of nf_conv_s.hip)
+def small16_cases():
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "small16.npz"))
+    return [str(c) for c in z["_cases"]]
+
+
+SMALL16_LIM = dict(xlim=(-3.0, 3.0), ylim=(-3.0, 3.0), extrap={'left': 'linear', 'right': 'linear'})
+
+
+def small16_nets(z, tag, n_nets=2, dtype=torch.float64):
+    nets = []
+    for k in range(n_nets):
+        layers = [(T(z[f"{tag}/param/nets.{k}.{i}.weight"]).to(dtype), T(z[f"{tag}/param/nets.{k}.{i}.bias"]).to(dtype)) for i in (0, 2, 4)]
+        nets.append(lambda x, layers=layers: O.conv_act(x, layers, ['tanh', 'tanh', None]))
+    return nets
+
+
+@pytest.mark.parametrize("tag", small16_cases())
+def test_small16_blocks_against_reference(golden, tag):
+    """Whole Coupling_ blocks on 2-D / 3-D lattices with a 16-site fastest axis, as the reference computes them
+    (tests/golden/make_golden_small16.py): the fixtures the small-lattice fused kernel is held to on the GPU."""
+    z = golden("small16")
+    kind = tag.split("/")[0]
+    shape = tuple(int(v) for v in z[f"{tag}/shape"])
+    opts = SMALL16_LIM if kind == "rqs" else {}
+    y, logJ = O.coupling_block(T(z[f"{tag}/x"]), small16_nets(z, tag), kind, shape, **opts)
+    close(y, z[f"{tag}/y"])
+    close(logJ, z[f"{tag}/logJ"])
+    xh, lrt = O.coupling_block(T(z[f"{tag}/y"]), small16_nets(z, tag), kind, shape, inverse=True, log0=T(z[f"{tag}/logJ"]), **opts)
+    close(xh, z[f"{tag}/x"], 1e-8)
+    close(lrt, np.zeros_like(z[f"{tag}/logJ"]), 1e-8)
