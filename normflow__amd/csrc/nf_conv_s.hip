@@ -336,12 +336,13 @@ __global__ __launch_bounds__(256, 1) void conv_small3d_kernel(SmallArgs A) {
 // ---------------------------------------------------------------------------------------------------------------------
 // The same layer with EIGHT waves in two roles, two waves per SIMD (K5s above holds all weights in every wave: ~420 registers,
 // one wave per SIMD, and its counters say it is bound by vector issue and latency, not by the matrix pipe: a wave's
-// dependent chains have nothing to hide behind).  Waves 0-3 ("AB"): stages A and B and the spline passes -- vector-heavy,
-// 80 weight registers; waves 4-7 ("C"): the last layer's 63 MFMAs per tile -- matrix-heavy, 168 weight registers.  Wave w
-// and wave w + 4 own the same tiles and share the logit scratch: C(t) writes half t & 1 of it between barriers, the AB wave
-// maps those sites one interval later.  Interval t (two barriers, as before):
-//     AB:  spline(t-1), request the field values of plane t, A(t+3) | bar | B(t+2)              | bar
-//     C :  first tile of C(t)                                       | bar | second tile of C(t) | bar
+// dependent chains have nothing to hide behind).  Waves 0-3 ("X"): stages A and B and the THIRD column tile of the last layer
+// (136 weight registers); waves 4-7 ("Y"): the first two column tiles and the spline passes (112 weight registers + the logit
+// column).  Wave w and wave w + 4 own the same site tiles and share the logit scratch: C(t) fills half t & 1 of it during
+// interval t (X: channels 32.., Y: channels 0 .. 31), Y maps those sites in the second phase of interval t + 1.
+// Interval t (two barriers, as before):
+//     X:  A(t+3), third column tile of C(t), first site tile   | bar | B(t+2), third column tile, second site tile       | bar
+//     Y:  column tiles 0, 1 of C(t), both site tiles           | bar | spline(t-1), request the field values of plane t  | bar
 // Ring hazards: C(t) reads H2[t-1 .. t+1] while B(t+2) writes slot t+2 = t-2 (mod 4); A(t+3) writes H1 slot t-1, last read by
 // B(t) one interval earlier.  (Tried: stage A moved to the C waves and run one interval ahead, two rows per phase -- the C
 // waves then need 256 registers + 60 bytes of scratch and the kernel is 10 % slower: 3.33 against 3.02 ms per config-3 step.)
@@ -481,63 +482,63 @@ __global__ __launch_bounds__(512, 1) void conv_small3d_kernel8(SmallArgs A) {
         *reinterpret_cast<f16x4 *>(d + HL) = lo;
       }
     };
-    double lacc = 0.0;
-    float xpre = 0.f;
-    int64_t spre = -1;
-    auto prefetch_x = [&](int z, int64_t sbase) {       // the field values of plane z's sites (this wave's tiles), one interval ahead
-      spre = -1;
-      const int u = lane;
-      if (z >= 0 && z < L0 && u < ntw * 16) {
-        const int T = w4 + 4 * (u >> 4), m_ = u & 15;
-        const int yrow = 2 * T + (m_ >> 3), qq = m_ & 7;
-        const int xsite = 2 * qq + ((A.parity + z + yrow) & 1);
-        spre = sbase + (int64_t(z) * L1 + yrow) * LX + xsite;
-        xpre = A.xa[spre];
+    // the third column tile of the last layer (logit channels 32 .. 47: the derivative logits' tail) is multiplied here, the
+    // first two by the other role: 21 of the 63 MFMAs per tile
+    constexpr bool XC = KIND == 0;
+    f16x8 x3h[7], x3l[7];
+    float x3b = 0.f;
+    int tapCx[7];
+    if constexpr (XC) {
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        x3h[i] = A.w3[((2 * 7 + i) * 2) * 64 + lane];
+        x3l[i] = A.w3[((2 * 7 + i) * 2 + 1) * 64 + lane];
+        const int k = 4 * i + g;
+        tapCx[i] = k < 27 ? (k / 9) | (((k / 3) % 3) << 2) | ((k % 3) << 4) : (1 | (1 << 2) | (1 << 4));
       }
-    };
-    auto spline = [&](int z) {                          // plane z's logits: half z & 1 of the shared scratch, written by wave w4 + 4
-      if (spre >= 0) {
-        const int u = (z & 1) * 32 + lane;
-        float val, logd;
-        if constexpr (KIND == 1) {
-          const float tt = pt[u], ss = fabsf(pt[PTS + u]);
-          val = INV ? (xpre - tt) * __expf(ss) : tt + xpre * __expf(-ss);
-          logd = INV ? ss : -ss;
-        } else if (A.P.m == M) {
-          RegCol<float, C> col;
+      x3b = (A.b3 && 32 + n < A.cout) ? A.b3[32 + n] : 0.f;
+    }
+    auto logits_tile_x = [&](int z, int nt) {
+      if constexpr (XC) {
+        const int T = w4 + 4 * nt;
+        if (T >= L1 / 2) return;
+        const int rr = n >> 3, q = n & 7;
+        const int yrow = 2 * T + rr;
+        const int xa = 2 * q + ((A.parity + z + yrow) & 1);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int c = 0; c < C; ++c) col[c] = pt[c * PTS + u];
-          rqs_site<float, M, INV>(col, A.P, xpre, val, logd);
-        } else if (A.P.m == 8) {
-          RegCol<float, 22> col;
-#pragma unroll
-          for (int c = 0; c < 22; ++c) col[c] = pt[c * PTS + u];
-          rqs_site<float, 8, INV>(col, A.P, xpre, val, logd);
-        } else {
-          LdsCol<float> col{pt + u, PTS};
-          rqs_site<float, 0, INV>(col, A.P, xpre, val, logd);
+        for (int i = 0; i < 7; ++i) {
+          const int yr = wrap1(yrow + ((tapCx[i] >> 2) & 3) - 1, L1);
+          const int xr = (xa + ((tapCx[i] >> 4) & 3) - 1) & (LX - 1);
+          const unsigned char *src = H2 + ring(z + (tapCx[i] & 3) - 1) + (yr * LX + xr) * 16;
+          const f16x8 fh = *reinterpret_cast<const f16x8 *>(src);
+          const f16x8 fl = *reinterpret_cast<const f16x8 *>(src + HL);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, x3h[i], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, x3h[i], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, x3l[i], acc, 0, 0, 0);
         }
-        A.y[spre] = val;
-        A.y[spre ^ 1] = 0.f;
-        lacc += double(logd);
+        const int ch = 32 + n;
+        if (ch < A.cout) {
+          f32x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[r] * kInvWScale + x3b;
+          *reinterpret_cast<f32x4 *>(pt + ch * PTS + (z & 1) * 32 + nt * 16 + 4 * g) = v;
+        }
       }
     };
     for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
       const int64_t sbase = b * int64_t(V);
       load_x(sbase);
-      lacc = 0.0;
-      spre = -1;
       lds_barrier();
       for (int t = t0; t <= L0; ++t) {
-        if (t >= 1) spline(t - 1);
-        prefetch_x(t, sbase);
+        const bool on = t >= 0 && t < L0;
         if (a_valid(t + 3)) stageA(t + 3);
+        if (on) logits_tile_x(t, 0);
         lds_barrier();
         if (b_valid(t + 2)) stageB(t + 2);
+        if (on) logits_tile_x(t, 1);
         lds_barrier();
       }
-      const double tot = wave_sum(lacc);
-      if (lane == 0) red[w4] = tot;
       lds_barrier();
       if (threadIdx.x == 0) A.logj[b] = float((A.log0 ? double(A.log0[b]) : 0.0) + ((red[0] + red[1]) + (red[2] + red[3])));
       lds_barrier();
@@ -545,18 +546,19 @@ __global__ __launch_bounds__(512, 1) void conv_small3d_kernel8(SmallArgs A) {
     return;
   }
 
-  // ================================================================================== waves 4-7: the last layer's logits
-  f16x8 b3h[7][NT], b3l[7][NT];
+  // ===================================================== waves 4-7: the last layer's first two column tiles, and the spline
+  constexpr int NTY = KIND == 1 ? 1 : 2;
+  f16x8 b3h[7][NTY], b3l[7][NTY];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NTY; ++t)
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
       b3h[i][t] = A.w3[((t * 7 + i) * 2) * 64 + lane];
       b3l[i][t] = A.w3[((t * 7 + i) * 2 + 1) * 64 + lane];
     }
-  float b3v[NT];
+  float b3v[NTY];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) b3v[t] = (A.b3 && 16 * t + n < A.cout) ? A.b3[16 * t + n] : 0.f;
+  for (int t = 0; t < NTY; ++t) b3v[t] = (A.b3 && 16 * t + n < A.cout) ? A.b3[16 * t + n] : 0.f;
   int tapC[7];
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
@@ -569,9 +571,9 @@ __global__ __launch_bounds__(512, 1) void conv_small3d_kernel8(SmallArgs A) {
     const int rr = n >> 3, q = n & 7;
     const int yrow = 2 * T + rr;
     const int xa = 2 * q + ((A.parity + z + yrow) & 1);
-    f32x4 acc[NT];
+    f32x4 acc[NTY];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NTY; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
       const int yr = wrap1(yrow + ((tapC[i] >> 2) & 3) - 1, L1);
@@ -580,14 +582,14 @@ __global__ __launch_bounds__(512, 1) void conv_small3d_kernel8(SmallArgs A) {
       const f16x8 fh = *reinterpret_cast<const f16x8 *>(src);
       const f16x8 fl = *reinterpret_cast<const f16x8 *>(src + HL);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
+      for (int t = 0; t < NTY; ++t) {
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, b3h[i][t], acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, b3h[i][t], acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, b3l[i][t], acc[t], 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < NTY; ++t) {
       const int ch = 16 * t + n;
       if (ch < A.cout) {
         f32x4 v;
@@ -597,17 +599,63 @@ __global__ __launch_bounds__(512, 1) void conv_small3d_kernel8(SmallArgs A) {
       }
     }
   };
+  double lacc = 0.0;
+  float xpre = 0.f;
+  int64_t spre = -1;
+  auto prefetch_x = [&](int z, int64_t sbase) {       // the field values of plane z's sites (this wave's tiles), one interval ahead
+    spre = -1;
+    const int u = lane;
+    if (z >= 0 && z < L0 && u < ntw * 16) {
+      const int T = w4 + 4 * (u >> 4), m_ = u & 15;
+      const int yrow = 2 * T + (m_ >> 3), qq = m_ & 7;
+      const int xsite = 2 * qq + ((A.parity + z + yrow) & 1);
+      spre = sbase + (int64_t(z) * L1 + yrow) * LX + xsite;
+      xpre = A.xa[spre];
+    }
+  };
+  auto spline = [&](int z) {                          // plane z's logits: half z & 1 of the shared scratch, written by wave w4 + 4
+    if (spre >= 0) {
+      const int u = (z & 1) * 32 + lane;
+      float val, logd;
+      if constexpr (KIND == 1) {
+        const float tt = pt[u], ss = fabsf(pt[PTS + u]);
+        val = INV ? (xpre - tt) * __expf(ss) : tt + xpre * __expf(-ss);
+        logd = INV ? ss : -ss;
+      } else if (A.P.m == M) {
+        RegCol<float, C> col;
+#pragma unroll
+        for (int c = 0; c < C; ++c) col[c] = pt[c * PTS + u];
+        rqs_site<float, M, INV>(col, A.P, xpre, val, logd);
+      } else if (A.P.m == 8) {
+        RegCol<float, 22> col;
+#pragma unroll
+        for (int c = 0; c < 22; ++c) col[c] = pt[c * PTS + u];
+        rqs_site<float, 8, INV>(col, A.P, xpre, val, logd);
+      } else {
+        LdsCol<float> col{pt + u, PTS};
+        rqs_site<float, 0, INV>(col, A.P, xpre, val, logd);
+      }
+      A.y[spre] = val;
+      A.y[spre ^ 1] = 0.f;
+      lacc += double(logd);
+    }
+  };
   for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
     const int64_t sbase = b * int64_t(V);
     load_x(sbase);
+    lacc = 0.0;
+    spre = -1;
     lds_barrier();
     for (int t = t0; t <= L0; ++t) {
       const bool on = t >= 0 && t < L0;
-      if (on) logits_tile(t, 0);
+      if (on) { logits_tile(t, 0); logits_tile(t, 1); }
       lds_barrier();
-      if (on) logits_tile(t, 1);
+      if (t >= 1) spline(t - 1);          // plane t-1: all three column tiles were complete at the interval's first barrier... of the interval before
+      prefetch_x(t, sbase);
       lds_barrier();
     }
+    const double tot = wave_sum(lacc);
+    if (lane == 0) red[w4] = tot;
     lds_barrier();
     lds_barrier();
   }
