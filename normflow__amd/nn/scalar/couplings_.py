@@ -202,7 +202,7 @@ class Coupling_(Module_, ABC):
         if not _hip.load().nf_small_lattice_supported((C.c_int32 * len(lat))(*lat), len(lat), kind, cout, m, acts[0], acts[1]):
             return None
         B = x_active.shape[0]
-        l0 = _hip._log0_tensor(log0, x_active.reshape(B, -1), B)
+        l0 = _hip._log0_tensor(log0, x_active, B)
         return _hip.small_lattice_coupling(kind, x_frozen, x_active, packed, biases, l0, a, cout, acts, opts, inverse)
 
     def _slabs(self, B, per_sample_bytes, budget=None):
@@ -404,7 +404,7 @@ class RQSplineCoupling_(Coupling_):
         if cout != n_out or not _hip.load().nf_small3d_rqs_supported((C.c_int32 * 3)(*lat), cout, m, acts[0], acts[1]):
             return None
         B = x_active.shape[0]
-        l0 = _hip._log0_tensor(log0, x_active.reshape(B, -1), B)
+        l0 = _hip._log0_tensor(log0, x_active, B)
         opts = _hip.make_rqs_opts(m, self.xlim, self.ylim, self.extrap, _hip.LAYOUT_PAIR)
         return _hip.small3d_rqs(x_frozen, x_active, packed, biases, l0, a, cout, acts, opts, inverse)
 

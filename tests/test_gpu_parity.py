@@ -2326,3 +2326,51 @@ def test_small_lattice_kernel_against_reference_goldens(golden, tag, parity_repo
     assert rel(y2, z[f"{tag}/y"]) <= 2e-5                      # the inverse, through its forward residual
     if kind == "affine":
         assert rel(xh, z[f"{tag}/x"]) <= 2e-5 and float(lrt.abs().max()) <= 2e-5 * max(1.0, float(np.abs(z[f"{tag}/logJ"]).max()))
+
+
+def test_small_lattice_kernel_edge_cases():
+    """nf_small_lattice_coupling at its edges: empty batch, one sample, far more samples than workgroups (persistent loop),
+    non-contiguous inputs, both kernel forms (NF_OPT_SMALL8 on / off) bitwise equal per sample, unsupported shapes fall back
+    to the other kernels with the same results, CPU tensors refused."""
+    torch.manual_seed(5)
+    shape, m = (2, 4, 16), 16
+    net = ConvAct(1, 3 * m - 2, 3, conv_dim=3, hidden_sizes=[8, 8], acts=['tanh', 'tanh', None]).to(DEV, torch.float32)
+    with torch.no_grad():
+        for p_ in list(net.parameters())[-2:]:
+            p_.mul_(0.3)
+    mask = EvenOddMask(shape=shape)
+    lim = dict(xlim=(-4.0, 4.0), ylim=(-4.0, 4.0), extrap={'left': 'linear', 'right': 'linear'})
+    cpl = RQSplineCoupling_([net, net], mask=mask, **lim).to(DEV)
+    with torch.no_grad():
+        # empty batch
+        x0 = torch.empty((0,) + shape, device=DEV, dtype=torch.float32)
+        y0, l0 = cpl(x0)
+        assert y0.shape == x0.shape and l0.shape == (0,)
+        # one sample / many samples, and the two kernel forms
+        x = 1.2 * torch.randn((1500,) + shape, device=DEV, dtype=torch.float32)
+        y, lj = cpl(x)
+        y1, l1 = cpl(x[:1])
+        assert torch.equal(y1, y[:1]) and torch.equal(l1, lj[:1])
+        with _hip.options(small8=False):
+            y4, l4 = cpl(x)
+        assert rel(y4, y) <= 2e-6 and rel(l4, lj) <= 2e-6           # same arithmetic per site, another summation order of log|J|
+        # non-contiguous input (a strided view): same result as its contiguous copy
+        xs = torch.randn((40,) + shape + (2,), device=DEV, dtype=torch.float32)[..., 0]
+        assert not xs.is_contiguous()
+        ya, la = cpl(xs)
+        yb, lb = cpl(xs.contiguous())
+        assert torch.equal(ya, yb) and torch.equal(la, lb)
+        # a lattice the kernel does not take (fastest axis 8): the other kernels, same API
+        mask8 = EvenOddMask(shape=(2, 4, 8))
+        cpl8 = RQSplineCoupling_([net, net], mask=mask8, **lim).to(DEV)
+        x8 = torch.randn((3, 2, 4, 8), device=DEV, dtype=torch.float32)
+        assert cpl8._small3d_atom(False, mask8.purify(x8, 0), mask8.purify(x8, 1), mask8.checkerboard_parity(0), net, 0, 3 * m - 2) is None
+        y8, l8 = cpl8(x8)
+        xb8, lb8 = cpl8.backward(y8, l8)
+        y8b, _ = cpl8(xb8)
+        assert rel(y8b, y8) <= 1e-4
+    with pytest.raises(_hip.NormflowHipError):
+        packed, biases, acts, cout = net.small3d_plan()
+        cpu0 = torch.zeros((1,) + shape, device='cpu', dtype=torch.float32)
+        _hip.small_lattice_coupling(0, cpu0, cpu0, packed, biases, None, 0, cout, acts,
+                                    _hip.make_rqs_opts(m, (-4, 4), (-4, 4), lim["extrap"], _hip.LAYOUT_PAIR), False)
