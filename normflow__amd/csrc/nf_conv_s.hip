@@ -42,7 +42,7 @@ constexpr int RING = 4;           // planes kept of each hidden layer
 constexpr int C = 46, M = 16;     // most logit channels / knots (3 column tiles)
 constexpr int PTS = 68;           // floats per channel row of a wave's logit scratch: 2 planes x 32 sites + 4 (bank spread, 16-B rows)
 constexpr int PTW = 48 * PTS * 4; // bytes of a wave's logit scratch
-constexpr float kWScale = 1024.0f, kInvWScale = 1.0f / 1024.0f;
+constexpr float kInvWScale = 1.0f / 1024.0f;       // the host packs the weights scaled by 2^10 (normflow__amd/_hip.py: SPLIT16_WEIGHT_SCALE)
 constexpr int PX = LX + 2;        // the input field is kept with a one-site periodic halo on every axis: taps are plain offsets
 __host__ __device__ constexpr size_t x_bytes(int L0, int L1) { return ((size_t(L0 + 2) * (L1 + 2) * PX * 2 + 15) / 16) * 16; }   // one half array (hi or lo)
 __host__ __device__ constexpr size_t lds_bytes(int L0, int L1) {
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(512, 1) void conv_small3d_kernel8(SmallArgs A) {
       xpre = A.xa[spre];
     }
   };
-  auto spline = [&](int z) {                          // plane z's logits: half z & 1 of the shared scratch, written by wave w4 + 4
+  auto spline = [&](int z) {                          // plane z's logits: half z & 1 of the scratch shared with wave w4 (its third column tile)
     if (spre >= 0) {
       const int u = (z & 1) * 32 + lane;
       float val, logd;
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(512, 1) void conv_small3d_kernel8(SmallArgs A) {
       const bool on = t >= 0 && t < L0;
       if (on) { logits_tile(t, 0); logits_tile(t, 1); }
       lds_barrier();
-      if (t >= 1) spline(t - 1);          // plane t-1: all three column tiles were complete at the interval's first barrier... of the interval before
+      if (t >= 1) spline(t - 1);          // plane t-1: its three column tiles were complete when interval t-1 ended
       prefetch_x(t, sbase);
       lds_barrier();
     }
