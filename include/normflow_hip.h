@@ -496,6 +496,19 @@ int nf_conv_last_logits_split16(const void *in, int in_split16, const void *wspl
  * to the full lattice (rows, V), zeros at the sites of the other parity; rows = B * channels; lattice[3] even. */
 int nf_expand_pairs(const void *compact, void *full, int64_t rows, const int32_t *lattice, int parity, int dtype,
                     void *stream);
+/* nf_conv_wgrad_sites: the same gradient (same gw layout and accumulate-into-gw contract as nf_conv_wgrad) for layers with
+ * FEW columns -- taps x cin + 1 <= 224, i.e. every 1-, 2- and 3-D 3-tap layer of up to 8 input channels: the layers of the
+ * small lattices flows are usually trained on (reference: src/_normflowcore.py:275-294 differentiating
+ * src/nn/scalar/modules.py:120-145).  Every wave holds all column tiles and the waves split the sites of a box; no atomics --
+ * per-workgroup partial matrices in `workspace` (nf_conv_wgrad_sites_workspace bytes) are added to gw in a fixed order, so the
+ * gradient is bitwise reproducible.  compact_parity 0 / 1: gz is the pair-compact (B, cout, V/2) cotangent of an active-site-only
+ * layer (values at the sites whose coordinate sum == parity mod 2; needs an even fastest axis) and only those sites are
+ * walked; -1: gz is (B, cout, V).  fp32 and fp64 (fp64 with cout > 32 only up to 96 columns). */
+int nf_conv_wgrad_sites_supported(const int32_t *lattice, const int32_t *ksize, int cin, int cout, int dtype);
+size_t nf_conv_wgrad_sites_workspace(const int32_t *ksize, int cin, int cout, int dtype);
+int nf_conv_wgrad_sites(const void *in, const void *gz, void *gw, int64_t B, const int32_t *lattice, const int32_t *ksize,
+                        int cin, int cout, int compact_parity, void *workspace, size_t workspace_bytes, int dtype,
+                        void *stream);
 int nf_conv_wgrad_split16_supported(const int32_t *lattice, const int32_t *ksize, int cin, int cout);
 size_t nf_conv_wgrad_split16_workspace(int64_t B, const int32_t *lattice, int cin);
 int nf_conv_wgrad_split16(const void *in, const void *gz, void *gw, int64_t B, const int32_t *lattice,

@@ -15,4 +15,4 @@ from . import prior
 from . import mcmc
 
 __version__ = "0.1.0"
-from .graphs import GraphedFlow
+from .graphs import GraphedFlow, GraphedTrainStep

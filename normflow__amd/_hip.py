@@ -79,6 +79,9 @@ PROTOTYPES = {
     "nf_absmax_bits": (_I, [_P, _I64, _P, _P]),
     "nf_conv_last_logits_split16": (_I, [_P, _I, _P, _P, _P, _I64, C.POINTER(C.c_int32), _I, _P, _P]),
     "nf_expand_pairs": (_I, [_P, _P, _I64, C.POINTER(C.c_int32), _I, _I, _P]),
+    "nf_conv_wgrad_sites_supported": (_I, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I]),
+    "nf_conv_wgrad_sites_workspace": (_SZ, [C.POINTER(C.c_int32), _I, _I, _I]),
+    "nf_conv_wgrad_sites": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I, _P, _SZ, _I, _P]),
     "nf_conv_wgrad_split16_supported": (_I, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I]),
     "nf_conv_wgrad_split16_workspace": (_SZ, [_I64, C.POINTER(C.c_int32), _I]),
     "nf_conv_wgrad_split16": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _P, _I, _P, _SZ, _P]),
@@ -759,6 +762,21 @@ def invalidate_weight_checks():
 
 
 _PACKED = {}
+_PACK_IN_CAPTURE = [False]
+
+
+class pack_inside_capture:
+    """While active, a stream capture never takes a cached fragment packing: the repacking kernels are captured with the
+    pass, so a graph that is replayed across optimiser steps (graphs.GraphedTrainStep) always multiplies by the CURRENT
+    weights.  (GraphedFlow, an inference graph, keeps the cached packing out of its graph and re-captures instead.)"""
+
+    def __enter__(self):
+        self._old = _PACK_IN_CAPTURE[0]
+        _PACK_IN_CAPTURE[0] = True
+
+    def __exit__(self, *exc):
+        _PACK_IN_CAPTURE[0] = self._old
+        return False
 
 
 def _cached_pack(w, kind, fn):
@@ -766,6 +784,8 @@ def _cached_pack(w, kind, fn):
     parameter a view like Conv4d.weight is based on, held by weak reference as in `_weights_fit_fp16`) and version, so that
     an inference pass does not repack (a dozen small torch kernels per layer and launch) weights that have not changed.
     A detached alias or a temporary has no live base: it is packed every time."""
+    if _PACK_IN_CAPTURE[0] and torch.cuda.is_current_stream_capturing():
+        return fn(w.detach())          # a training graph: the packing is part of the graph, replayed on the current values
     base = w._base if w._base is not None else w
     key = (id(base), kind)
     state = (w._version, w.data_ptr(), tuple(w.shape), w.dtype)
@@ -872,10 +892,11 @@ def absmax_bits(t):
 
 def conv_weight_grad(x, gz, ksize, bits=None, compact_parity=-1):
     """(grad_weight (cout, cin, *k), grad_bias (cout)) of a circular conv layer from its input x
-    (B, cin, *L) and the full-lattice pre-activation cotangent gz (B, cout, *L): nf_conv_wgrad, or nf_conv_wgrad_split16
-    (`bits`: absmax_bits(gz) if the caller has it already).  compact_parity 0 / 1: gz is the pair-compact (B, cout, V/2)
-    cotangent of an active-site-only layer; only the split-fp16 kernel reads that form: None is returned when the shape does
-    not qualify (the caller expands gz and calls again)."""
+    (B, cin, *L) and the full-lattice pre-activation cotangent gz (B, cout, *L): nf_conv_wgrad_split16 (4-D lattice networks;
+    `bits`: absmax_bits(gz) if the caller has it already), nf_conv_wgrad_sites (layers of few columns: 1- to 3-D kernels;
+    bitwise reproducible) or nf_conv_wgrad.  compact_parity 0 / 1: gz is the pair-compact (B, cout, V/2) cotangent of an
+    active-site-only layer; the first two kernels read that form: None is returned when the shape does not qualify (the
+    caller expands gz and calls again)."""
     lib = load()
     B, cin = x.shape[:2]
     cout = gz.shape[1]
@@ -892,7 +913,10 @@ def conv_weight_grad(x, gz, ksize, bits=None, compact_parity=-1):
         buf = torch.zeros(((c1 - c0 + 15) // 16) * 16, ncols, dtype=x.dtype, device=x.device)
         split = (x.dtype == torch.float32 and lib.nf_get_option(OPT_SPLIT16)
                  and lib.nf_conv_wgrad_split16_supported(lat4, k4, cin, c1 - c0))
-        if compact_parity >= 0 and not split:
+        sites = not split and bool(lib.nf_conv_wgrad_sites_supported(lat4, k4, cin, c1 - c0, _dtype_code(x)))
+        if compact_parity >= 0 and not (split or sites):
+            return None
+        if compact_parity >= 0 and sites and x.shape[-1] % 2:
             return None
         for b0 in range(0, B, MAX_B):
             b1 = min(B, b0 + MAX_B)
@@ -904,6 +928,12 @@ def conv_weight_grad(x, gz, ksize, bits=None, compact_parity=-1):
                 _check(lib.nf_conv_wgrad_split16(_ptr(x[b0:b1]), _ptr(part[b0:b1]), _ptr(buf), b1 - b0, lat4, k4, cin,
                                                  c1 - c0, _ptr(bits), int(compact_parity), _ptr(ws), ws.numel(), _stream()),
                        "nf_conv_wgrad_split16")
+            elif sites:     # few columns (1- to 3-D kernels): the waves split the sites, fixed-order sums (nf_conv.hip)
+                need = lib.nf_conv_wgrad_sites_workspace(k4, cin, c1 - c0, _dtype_code(x))
+                ws = torch.empty(int(need), dtype=torch.uint8, device=x.device)
+                _check(lib.nf_conv_wgrad_sites(_ptr(x[b0:b1]), _ptr(part[b0:b1]), _ptr(buf), b1 - b0, lat4, k4, cin,
+                                               c1 - c0, int(compact_parity), _ptr(ws), ws.numel(), _dtype_code(x), _stream()),
+                       "nf_conv_wgrad_sites")
             else:
                 _check(lib.nf_conv_wgrad(_ptr(x[b0:b1]), _ptr(part[b0:b1]), _ptr(buf), b1 - b0, lat4, k4, cin,
                                          c1 - c0, _dtype_code(x), _stream()), "nf_conv_wgrad")
@@ -1041,10 +1071,11 @@ class ConvFn(torch.autograd.Function):
         kdims = list(range(2, weight.dim()))
         wt = weight.detach().flip(kdims).transpose(0, 1).contiguous() if ctx.needs_input_grad[0] else None
         gx = gw = gb = None
-        if ctx.compact and split_ok:
-            # the pair-compact cotangent as it is: the split-fp16 kernels read that form, no expanded copy
+        if ctx.compact:
+            # the pair-compact cotangent as it is: the split-fp16 kernels and the few-column weight-gradient kernel read that
+            # form, no expanded copy
             gzc = gz.reshape(x.shape[0], weight.shape[0], -1).contiguous()
-            if wt is not None:
+            if wt is not None and split_ok:
                 gx = conv_input_grad_split16(gzc, wt, bits, ctx.parity, lattice, weight)
             if want_w:
                 got = conv_weight_grad(x, gzc, weight.shape[2:], bits, ctx.parity)

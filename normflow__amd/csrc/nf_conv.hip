@@ -838,6 +838,8 @@ struct WgArgs {
   int L[4], k[4], box[4], lbox[4], nbox[4], hal[4];
   int S, PS, units;     // in-tile plane stride, gz-tile plane stride, sites per box
   int cin, cout, ntot, ncols_pad, nt0, nboxes;
+  int parity;           // conv_wgrad_sites_kernel: >= 0: gz is pair-compact (B, cout, V/2), values at the active sites of this parity
+  void *part;           // conv_wgrad_sites_kernel: (gridDim.x, MTW * 16, ncols_pad) partial sums, one slot per workgroup
 };
 
 template <typename T> __device__ __forceinline__ void atomic_add(T *p, T v) { atomicAdd(p, v); }
@@ -962,6 +964,207 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(WgArgs A) {
     }
 }
 
+constexpr int kSitesStage = 10;                // input elements a thread stages per channel (a halo plane of <= 2560 elements)
+
+// The same GEMM for layers with FEW columns (N = taps x cin + 1 <= 14 tiles: 1-, 2- and 3-D kernels), where the split of
+// the column tiles over the waves above leaves most waves idle (14 tiles over 4 x 6 slots: 2.3 waves of 4 work; 2 tiles: one
+// wave): every wave holds ALL column tiles and the waves split the SITES of a box (K) instead.  A pair-compact cotangent
+// (the layer that is evaluated at the active sites only) is read as it stands and only its active sites are walked: half
+// the K steps, no expanded copy.  No atomics: the four waves add up through LDS in a fixed order, every workgroup stores one
+// partial matrix, wgrad_sites_reduce_kernel adds them to gw in workgroup order -- the gradient is bitwise reproducible.
+template <typename T, int MTW, int NTW>
+__global__ __launch_bounds__(kBlock) void conv_wgrad_sites_kernel(WgArgs A) {
+  typedef typename Mma<T>::vec4 acc_t;
+  extern __shared__ __align__(16) unsigned char smem_conv[];
+  T *tile = reinterpret_cast<T *>(smem_conv);                 // cin planes of the box + halo
+  T *gzt = tile + A.cin * A.S;                                // MTW*16 planes of the box's K entries
+  const int h0 = A.hal[0], h1 = A.hal[1], h2 = A.hal[2], h3 = A.hal[3];
+  const int R = h0 * h1 * h2;
+  int *rowsrc = reinterpret_cast<int *>(gzt + MTW * 16 * A.PS);
+  const int lane = threadIdx.x & 63, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int nwaves = kBlock / kWave;
+  const int r0 = A.k[0] >> 1, r1 = A.k[1] >> 1, r2 = A.k[2] >> 1, r3 = A.k[3] >> 1;
+  const bool compact = A.parity >= 0;
+  const int KU = compact ? A.units >> 1 : A.units;            // K entries of a box: its sites, or its active sites (a power of two)
+  const int lKU = 31 - __builtin_clz(unsigned(KU));
+  const int lb3 = compact ? A.lbox[3] - 1 : A.lbox[3];        // bits of the position along the fastest axis (pairs / sites)
+  const int64_t gzV = compact ? A.V >> 1 : A.V;
+
+  int coff[NTW];
+  bool one[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    const int n = (nt << 4) + (lane & 15);
+    coff[nt] = 0;
+    one[nt] = n == A.ntot;
+    if (n < A.ntot) {
+      int tap = n / A.cin;
+      const int ci = n - tap * A.cin;
+      const int j3 = tap % A.k[3]; tap /= A.k[3];
+      const int j2 = tap % A.k[2]; tap /= A.k[2];
+      const int j1 = tap % A.k[1];
+      const int j0 = tap / A.k[1];
+      coff[nt] = ((j0 * h1 + j1) * h2 + j2) * h3 + j3 + ci * A.S;
+    }
+  }
+  acc_t acc[MTW][NTW];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = acc_t{T(0), T(0), T(0), T(0)};
+
+  // K entry ku of a box -> box coordinates (z0, z1, z2, z3); compact: entry = (row, pair), the pair's active site
+  auto decode = [&](int ku, const int *o, int &z0, int &z1, int &z2, int &z3) {
+    const int p = ku & ((1 << lb3) - 1);
+    int u = ku >> lb3;
+    z2 = u & (A.box[2] - 1); u >>= A.lbox[2];
+    z1 = u & (A.box[1] - 1); u >>= A.lbox[1];
+    z0 = u;
+    z3 = compact ? 2 * p + ((o[0] + z0 + o[1] + z1 + o[2] + z2 + A.parity) & 1) : p;
+  };
+
+  // staging of the input box: element e = threadIdx + 256 j of the (halo rows x fastest-axis positions) plane of a channel
+  // -- every lane loads (a row of the halo has 6 .. 34 positions: a wave per row left most lanes idle), and a thread's
+  // loads of one channel are issued together, then stored (one load per round trip was the kernel's time).  The split of
+  // e into (row, position) does not depend on the item.
+  constexpr int ES = kSitesStage;                      // >= ceil(halo plane / 256): checked by the launcher
+  const int plane = R * h3;
+  int er[ES], ez[ES];
+#pragma unroll
+  for (int j = 0; j < ES; ++j) {
+    const int e = int(threadIdx.x) + kBlock * j;
+    er[j] = e < plane ? e / h3 : -1;
+    ez[j] = e < plane ? e - er[j] * h3 : 0;
+  }
+
+  for (int64_t item = blockIdx.x; item < A.nitems; item += gridDim.x) {
+    const int b = int(item / A.nboxes);
+    int bid = int(item - int64_t(b) * A.nboxes);
+    int o[4];
+#pragma unroll
+    for (int mu = 3; mu >= 0; --mu) {
+      o[mu] = (bid % A.nbox[mu]) * A.box[mu];
+      bid /= A.nbox[mu];
+    }
+    const T *__restrict__ in_b = static_cast<const T *>(A.in) + int64_t(b) * A.cin * A.V;
+    const T *__restrict__ gz_b = static_cast<const T *>(A.gz) + int64_t(b) * A.cout * gzV;
+    __syncthreads();                                  // previous item fully consumed
+    for (int t = threadIdx.x; t < R; t += kBlock) {
+      const int z0 = t / (h1 * h2), rem = t - z0 * (h1 * h2);
+      const int z1 = rem / h2, z2 = rem - z1 * h2;
+      const int x0 = wrap(o[0] + z0 - r0, A.L[0]), x1 = wrap(o[1] + z1 - r1, A.L[1]),
+                x2 = wrap(o[2] + z2 - r2, A.L[2]);
+      rowsrc[t] = ((x0 * A.L[1] + x1) * A.L[2] + x2) * A.L[3];
+    }
+    // the cotangent's K entries, eight loads in flight per thread
+    for (int base = threadIdx.x; base < ((MTW * 16) << lKU); base += 8 * kBlock) {
+      T v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int idx = base + j * kBlock;
+        const int co = idx >> lKU, ku = idx & (KU - 1);
+        int z0, z1, z2, z3;
+        decode(ku, o, z0, z1, z2, z3);
+        const int x0 = o[0] + z0, x1 = o[1] + z1, x2 = o[2] + z2, x3 = o[3] + z3;
+        v[j] = T(0);
+        if (idx < ((MTW * 16) << lKU) && co < A.cout && x0 < A.L[0] && x1 < A.L[1] && x2 < A.L[2] && x3 < A.L[3]) {
+          const int64_t flat = ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * A.L[3] + x3;
+          v[j] = gz_b[int64_t(co) * gzV + (compact ? flat >> 1 : flat)];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int idx = base + j * kBlock;
+        if (idx < ((MTW * 16) << lKU)) gzt[(idx >> lKU) * A.PS + (idx & (KU - 1))] = v[j];
+      }
+    }
+    __syncthreads();                                  // row table visible
+    int esrc[ES];
+#pragma unroll
+    for (int j = 0; j < ES; ++j)
+      esrc[j] = er[j] >= 0 ? rowsrc[er[j]] + wrap(o[3] + ez[j] - r3, A.L[3]) : -1;
+    for (int c = 0; c < A.cin; ++c) {
+      T v[ES];
+#pragma unroll
+      for (int j = 0; j < ES; ++j) v[j] = esrc[j] >= 0 ? in_b[int64_t(c) * A.V + esrc[j]] : T(0);
+#pragma unroll
+      for (int j = 0; j < ES; ++j)
+        if (esrc[j] >= 0) tile[c * A.S + int(threadIdx.x) + kBlock * j] = v[j];
+    }
+    __syncthreads();
+    // K loop: the waves take turns over the box's K entries, 4 per MFMA
+    for (int s = 4 * wave; s < KU; s += 4 * nwaves) {
+      const int ku = s + g;
+      int z0, z1, z2, z3;
+      decode(ku, o, z0, z1, z2, z3);
+      const int ab = ((z0 * h1 + z1) * h2 + z2) * h3 + z3;
+      T a[MTW], bq[NTW];
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) a[mt] = gzt[((mt << 4) + (lane & 15)) * A.PS + ku];
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) bq[nt] = one[nt] ? T(1) : tile[ab + coff[nt]];
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = Mma<T>::mma(a[mt], bq[nt], acc[mt][nt]);
+    }
+  }
+  // waves 1..3 hand their sums to wave 0 through LDS, one accumulator tile at a time, added in wave order; wave 0 stores
+  // the workgroup's partial matrix: D col = lane & 15 (n), rows (co) 4g + r (f32) / g + 4r (f64)
+  T *xch = reinterpret_cast<T *>(smem_conv);             // [wave 1..3][lane][4]
+  T *part = static_cast<T *>(A.part) + int64_t(blockIdx.x) * (MTW * 16) * A.ncols_pad;
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      __syncthreads();
+      if (wave > 0)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xch[((wave - 1) * 64 + lane) * 4 + r] = acc[mt][nt][r];
+      __syncthreads();
+      const int n = (nt << 4) + (lane & 15);
+      if (wave == 0 && n < A.ncols_pad) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          T v = acc[mt][nt][r];
+          for (int w = 0; w < nwaves - 1; ++w) v += xch[(w * 64 + lane) * 4 + r];
+          const int co = (mt << 4) + (Mma<T>::kStridedRows ? g + (r << 2) : (g << 2) + r);
+          part[int64_t(co) * A.ncols_pad + n] = v;
+        }
+      }
+    }
+}
+
+// gw[i] += part[0][i] + part[1][i] + ... (i over the MTW * 16 x ncols_pad matrix), always in the same order: thread (i, j) of a
+// workgroup adds the slots of chunk j one after the other (eight loads in flight), the chunks' sums are added in chunk order.
+constexpr int kRedChunks = 16;
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_sites_reduce_kernel(const T *__restrict__ part, T *__restrict__ gw, int nslots, int64_t n) {
+  __shared__ T sums[256];
+  const int j = threadIdx.x >> 4, il = threadIdx.x & 15;
+  const int64_t i = int64_t(blockIdx.x) * 16 + il;
+  const int per = (nslots + kRedChunks - 1) / kRedChunks;
+  const int s0 = j * per, s1 = s0 + per < nslots ? s0 + per : nslots;
+  T v = T(0);
+  if (i < n) {
+    for (int sl = s0; sl < s1; sl += 8) {
+      T t[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t[q] = sl + q < s1 ? part[int64_t(sl + q) * n + i] : T(0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v += t[q];
+    }
+  }
+  sums[threadIdx.x] = v;
+  __syncthreads();
+  if (j == 0 && i < n) {
+    T tot = sums[il];
+    for (int c = 1; c < kRedChunks; ++c) tot += sums[c * 16 + il];
+    gw[i] += tot;
+  }
+}
+
 template <typename T, int MTW>
 static int launch_wgrad(const WgArgs &A0, int ntiles, size_t lds, int grid, hipStream_t stream) {
   WgArgs A = A0;
@@ -987,12 +1190,12 @@ static int launch_wgrad(const WgArgs &A0, int ntiles, size_t lds, int grid, hipS
   return NF_OK;
 }
 
+// box geometry, LDS layout and column count of a weight-gradient launch (both kernels)
 template <typename T>
-static int run_wgrad(const void *in, const void *gz, void *gw, int64_t B, const int32_t *lattice,
-                     const int32_t *ksize, int cin, int cout, hipStream_t stream) {
+static int wgrad_setup(WgArgs &A, const void *in, const void *gz, void *gw, int64_t B, const int32_t *lattice, const int32_t *ksize,
+                       int cin, int cout, int *ntiles_out, size_t *lds_out) {
   NF_REQUIRE(in && gz && gw && lattice && ksize, "nf_conv_wgrad: NULL pointer");
   NF_REQUIRE(B >= 0 && cin >= 1 && cout >= 1 && cout <= 48, "nf_conv_wgrad: bad sizes (cout <= 48 per call)");
-  WgArgs A{};
   int64_t V = 1;
   int ntaps = 1;
   for (int mu = 0; mu < 4; ++mu) {
@@ -1003,7 +1206,6 @@ static int run_wgrad(const void *in, const void *gz, void *gw, int64_t B, const 
     ntaps *= ksize[mu];
   }
   NF_REQUIRE(V < (int64_t(1) << 31), "nf_conv_wgrad: lattice volume must be < 2^31");
-  if (B == 0 || V == 0) return NF_OK;
   const int MTW = (cout + 15) >> 4;
   // box of 256 (fp32) / 128 (fp64) sites, same shape rule as the forward kernel
   const int target = sizeof(T) == 4 ? 256 : 128;
@@ -1040,12 +1242,89 @@ static int run_wgrad(const void *in, const void *gz, void *gw, int64_t B, const 
   A.nboxes = int(nboxes);
   A.nitems = int64_t(B) * nboxes;
   A.V = V; A.in = in; A.gz = gz; A.gw = gw;
+  A.parity = -1; A.part = nullptr;
   const size_t lds = (size_t(cin) * A.S + size_t(MTW) * 16 * A.PS) * sizeof(T) + size_t(rows) * 2 * sizeof(int);
   NF_REQUIRE(lds <= 160 * 1024, "nf_conv_wgrad: needs %zu B of LDS (> 160 KiB): cin=%d", lds, cin);
+  *ntiles_out = ntiles;
+  *lds_out = lds;
+  return NF_OK;
+}
+
+template <typename T>
+static int run_wgrad(const void *in, const void *gz, void *gw, int64_t B, const int32_t *lattice,
+                     const int32_t *ksize, int cin, int cout, hipStream_t stream) {
+  WgArgs A{};
+  int ntiles = 0;
+  size_t lds = 0;
+  const int rc = wgrad_setup<T>(A, in, gz, gw, B, lattice, ksize, cin, cout, &ntiles, &lds);
+  if (rc) return rc;
+  if (B == 0 || A.V == 0) return NF_OK;
+  const int MTW = (cout + 15) >> 4;
   const int grid = int(A.nitems < 512 ? A.nitems : 512);
   if (MTW == 1) return launch_wgrad<T, 1>(A, ntiles, lds, grid, stream);
   if (MTW == 2) return launch_wgrad<T, 2>(A, ntiles, lds, grid, stream);
   return launch_wgrad<T, 3>(A, ntiles, lds, grid, stream);
+}
+
+// the K-split kernel: layers of at most kSitesMaxTiles column tiles
+constexpr int kSitesMaxTiles = 14;
+constexpr int kSitesMaxGrid = 512;
+
+static int wgrad_sites_tiles(const int32_t *ksize, int cin) {
+  int64_t ntaps = 1;
+  for (int mu = 0; mu < 4; ++mu) {
+    if (ksize[mu] < 1 || !(ksize[mu] & 1)) return 0;
+    ntaps *= ksize[mu];
+    if (ntaps > 4096) return 0;
+  }
+  return int((ntaps * cin + 1 + 15) >> 4);
+}
+
+template <typename T, int MTW>
+static int launch_wgrad_sites(const WgArgs &A, int ntiles, size_t lds, int grid, hipStream_t stream) {
+#define NF_WGS(NTW)                                                                                        \
+  {                                                                                                        \
+    if (lds > 64 * 1024)                                                                                   \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_sites_kernel<T, MTW, NTW>),     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));                     \
+    hipLaunchKernelGGL((conv_wgrad_sites_kernel<T, MTW, NTW>), dim3(grid), dim3(kBlock), lds, stream, A);  \
+  }
+  if (ntiles <= 2) NF_WGS(2) else if (ntiles <= 6) NF_WGS(6) else NF_WGS(14)
+#undef NF_WGS
+  return check_launch("conv wgrad (sites) kernel");
+}
+
+template <typename T>
+static int run_wgrad_sites(const void *in, const void *gz, void *gw, int64_t B, const int32_t *lattice, const int32_t *ksize,
+                           int cin, int cout, int compact_parity, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+  WgArgs A{};
+  int ntiles = 0;
+  size_t lds = 0;
+  const int rc = wgrad_setup<T>(A, in, gz, gw, B, lattice, ksize, cin, cout, &ntiles, &lds);
+  if (rc) return rc;
+  NF_REQUIRE(ntiles <= kSitesMaxTiles, "nf_conv_wgrad_sites: %d column tiles (taps x cin + 1 must be <= %d)", ntiles, 16 * kSitesMaxTiles);
+  NF_REQUIRE(compact_parity < 0 || (lattice[3] % 2 == 0 && compact_parity <= 1), "nf_conv_wgrad_sites: a pair-compact cotangent needs an even fastest axis and parity 0 / 1");
+  if (B == 0 || A.V == 0) return NF_OK;
+  const int MTW = (cout + 15) >> 4;
+  const int grid = int(A.nitems < kSitesMaxGrid ? A.nitems : kSitesMaxGrid);
+  const int64_t n = int64_t(MTW) * 16 * A.ncols_pad;
+  NF_REQUIRE(workspace && workspace_bytes >= size_t(grid) * size_t(n) * sizeof(T), "nf_conv_wgrad_sites: workspace too small (nf_conv_wgrad_sites_workspace)");
+  A.parity = compact_parity;
+  A.part = workspace;
+  if (compact_parity >= 0) {                                  // half the K entries: a smaller cotangent tile (two workgroups per CU)
+    const size_t old_gz = size_t(MTW) * 16 * A.PS * sizeof(T);
+    A.PS = (A.units >> 1) + 2;
+    lds -= old_gz - size_t(MTW) * 16 * A.PS * sizeof(T);
+  }
+  if (lds < size_t(3) * 64 * 4 * sizeof(T)) lds = size_t(3) * 64 * 4 * sizeof(T);      // the waves' exchange at the end
+  int rc2;
+  if (MTW == 1) rc2 = launch_wgrad_sites<T, 1>(A, ntiles, lds, grid, stream);
+  else if (MTW == 2) rc2 = launch_wgrad_sites<T, 2>(A, ntiles, lds, grid, stream);
+  else rc2 = launch_wgrad_sites<T, 3>(A, ntiles, lds, grid, stream);
+  if (rc2) return rc2;
+  hipLaunchKernelGGL((wgrad_sites_reduce_kernel<T>), dim3(unsigned((n + 15) / 16)), dim3(256), 0, stream,
+                     static_cast<const T *>(workspace), static_cast<T *>(gw), grid, n);
+  return check_launch("conv wgrad (sites) reduce kernel");
 }
 
 // d(activation)/d(pre-activation) expressed through the activation's OUTPUT y
@@ -1077,6 +1356,45 @@ extern "C" int nf_conv_wgrad(const void *in, const void *gz, void *gw, int64_t B
   if (dtype == NF_F32) return run_wgrad<float>(in, gz, gw, B, lattice, ksize, cin, cout, s);
   if (dtype == NF_F64) return run_wgrad<double>(in, gz, gw, B, lattice, ksize, cin, cout, s);
   set_error("nf_conv_wgrad: unsupported dtype %d", dtype);
+  return NF_EINVAL;
+}
+
+// 1 if nf_conv_wgrad_sites takes a layer with this kernel and input-channel count (taps x cin + 1 columns in <= 14 tiles:
+// every 1-, 2- and 3-D 3-tap layer of up to 8 input channels)
+extern "C" int nf_conv_wgrad_sites_supported(const int32_t *lattice, const int32_t *ksize, int cin, int cout, int dtype) {
+  if (!lattice || !ksize || cin < 1 || cout < 1 || cout > 48 || (dtype != NF_F32 && dtype != NF_F64)) return 0;
+  const int nt = wgrad_sites_tiles(ksize, cin);
+  if (nt < 1 || nt > kSitesMaxTiles) return 0;
+  if (dtype == NF_F64 && cout > 32 && nt > 6) return 0;      // (3 x 14 fp64 accumulator tiles do not fit the register file)
+  int64_t V = 1;
+  for (int mu = 0; mu < 4; ++mu) {
+    if (lattice[mu] < 1) return 0;
+    V *= lattice[mu];
+  }
+  if (V >= (int64_t(1) << 31)) return 0;
+  WgArgs A{};
+  int ntiles = 0;
+  size_t lds = 0;
+  const int dummy = 0;
+  const int rc = dtype == NF_F32 ? wgrad_setup<float>(A, &dummy, &dummy, const_cast<int *>(&dummy), 1, lattice, ksize, cin, cout, &ntiles, &lds)
+                                 : wgrad_setup<double>(A, &dummy, &dummy, const_cast<int *>(&dummy), 1, lattice, ksize, cin, cout, &ntiles, &lds);
+  if (rc) return 0;
+  return int64_t(A.hal[0]) * A.hal[1] * A.hal[2] * A.hal[3] <= int64_t(kSitesStage) * kBlock;
+}
+
+extern "C" size_t nf_conv_wgrad_sites_workspace(const int32_t *ksize, int cin, int cout, int dtype) {
+  if (!ksize || cin < 1 || cout < 1 || cout > 48 || wgrad_sites_tiles(ksize, cin) > kSitesMaxTiles) return 0;
+  return size_t(kSitesMaxGrid) * size_t((cout + 15) / 16 * 16) * size_t(wgrad_sites_tiles(ksize, cin) * 16) * (dtype == NF_F64 ? 8 : 4);
+}
+
+extern "C" int nf_conv_wgrad_sites(const void *in, const void *gz, void *gw, int64_t B, const int32_t *lattice,
+                                   const int32_t *ksize, int cin, int cout, int compact_parity, void *workspace,
+                                   size_t workspace_bytes, int dtype, void *stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  NF_REQUIRE(lattice && ksize && nf_conv_wgrad_sites_supported(lattice, ksize, cin, cout, dtype), "nf_conv_wgrad_sites: layer not supported (nf_conv_wgrad_sites_supported)");
+  if (dtype == NF_F32) return run_wgrad_sites<float>(in, gz, gw, B, lattice, ksize, cin, cout, compact_parity, workspace, workspace_bytes, s);
+  if (dtype == NF_F64) return run_wgrad_sites<double>(in, gz, gw, B, lattice, ksize, cin, cout, compact_parity, workspace, workspace_bytes, s);
+  set_error("nf_conv_wgrad_sites: unsupported dtype %d", dtype);
   return NF_EINVAL;
 }
 

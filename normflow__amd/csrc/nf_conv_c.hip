@@ -41,9 +41,10 @@ constexpr int LDS_BYTES = NPL * PLANE;                      // 23040
 constexpr float kInvWScale = 1.0f / 1024.0f;
 }  // namespace c2
 
-__device__ __forceinline__ float tanh_affine_c(float a, float c1, float c0) {
+// tanh / logistic of a * scale + bias in one branch-free form: al / (1 + 2^(c1 a + c0)) + ga (nf_conv_g.hip, act_affine)
+__device__ __forceinline__ float act_affine_c(float a, float c1, float c0, float al, float ga) {
   const float t = __builtin_amdgcn_exp2f(__builtin_fmaf(a, c1, c0));
-  return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + t), 1.0f);
+  return __builtin_fmaf(al, __builtin_amdgcn_rcpf(1.0f + t), ga);
 }
 
 // C0 x C1 = rows of the cross-section (2 or 4 each)
@@ -90,9 +91,13 @@ __global__ __launch_bounds__(512, 2) void conv_c2_kernel(ConvArgs A) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     bv4[r] = A.bias ? static_cast<const float *>(A.bias)[4 * (g & 1) + r] : 0.f;
-    kc0[r] = 2.885390081777927f * bv4[r];
   }
-  const float kc1 = 2.885390081777927f * kInvWScale;
+  const bool is_tanh = A.act != kActSigmoid;
+  const float kcs = is_tanh ? 2.885390081777927f : -1.4426950408889634f;       // 2 log2(e) / -log2(e)
+  const float kal = is_tanh ? -2.0f : 1.0f, kga = is_tanh ? 1.0f : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) kc0[r] = kcs * bv4[r];
+  const float kc1 = kcs * kInvWScale;
 
   // ---- A fragments.  K index = 4 r + t: kernel row r = (j0 * 3 + j1) * 3 + j2 (27, padded to 32 with zero weights), tap t of
   // the pair (sites 2p - 1 .. 2p + 2).  Slice sl, k-group g: rows rA = 8 sl + 2 g and rA + 1.  Lane (p, g) reads, for each, the
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void conv_c2_kernel(ConvArgs A) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float a = am[t][r] + ac[t][r];
-            const float v = A.act == kActTanh ? tanh_affine_c(a, kc1, kc0[r]) : activate(a * kInvWScale + bv4[r], kActSigmoid);
+            const float v = act_affine_c(a, kc1, kc0[r], kal, kga);
             const _Float16 h0 = static_cast<_Float16>(v);
             hi[r] = h0;
             lo[r] = static_cast<_Float16>(v - static_cast<float>(h0));

@@ -63,6 +63,13 @@ __device__ __forceinline__ float tanh_affine(float a, float c1, float c0) {
   const float t = __builtin_amdgcn_exp2f(__builtin_fmaf(a, c1, c0));
   return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + t), 1.0f);
 }
+// The two activations of the chain in ONE branch-free form: al / (1 + 2^(c1 a + c0)) + ga -- tanh: (al, ga) = (-2, 1) and
+// c = 2 log2(e) (scale, bias); logistic: (1, 0) and c = -log2(e) (scale, bias).  (A select on the run-time activation code
+// around every element had become a tree of scalar branches in the epilogue.)
+__device__ __forceinline__ float act_affine(float a, float c1, float c0, float al, float ga) {
+  const float t = __builtin_amdgcn_exp2f(__builtin_fmaf(a, c1, c0));
+  return __builtin_fmaf(al, __builtin_amdgcn_rcpf(1.0f + t), ga);
+}
 
 // EPI = 0: bias + activation -> the pair tensor (a hidden layer).  EPI = 1 / 2: the LAST layer of an affine coupling's net
 // (output channel 0 = t, 1 = s; the other six columns carry zero weights) fused with the coupling itself
@@ -127,9 +134,13 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     bv4[r] = A.bias ? static_cast<const float *>(A.bias)[4 * (g & 1) + r] : 0.f;
-    kc0[r] = 2.885390081777927f * bv4[r];      // 2 log2(e) x bias
   }
-  const float kc1 = 2.885390081777927f * kInvWScale;
+  const bool is_tanh = A.act != kActSigmoid;
+  const float kcs = is_tanh ? 2.885390081777927f : -1.4426950408889634f;       // 2 log2(e) / -log2(e)
+  const float kal = is_tanh ? -2.0f : 1.0f, kga = is_tanh ? 1.0f : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) kc0[r] = kcs * bv4[r];
+  const float kc1 = kcs * kInvWScale;
   [[maybe_unused]] const float descale = kInvWScale / pow2_scale_for(A.gscale_bits);      // EPI = 3
 
   // ---- A-fragment addressing.  Lane (pair p, k-group g) reads tap g of its pair q = 16 hs + p: site 2q + g - 1 -- parity block
@@ -272,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float a = prev[r] + pa[r];
-        const float v = A.act == kActTanh ? tanh_affine(a, kc1, kc0[r]) : activate(a * kInvWScale + bv4[r], kActSigmoid);
+        const float v = act_affine(a, kc1, kc0[r], kal, kga);
         const _Float16 h0 = static_cast<_Float16>(v);
         hi[r] = h0;
         lo[r] = static_cast<_Float16>(v - static_cast<float>(h0));

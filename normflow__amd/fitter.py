@@ -77,9 +77,15 @@ class Fitter:
         self.hyperparam = dict(lr=0.001, weight_decay=0.01)
         self.checkpoint_dict = dict(display=False, print_stride=100, print_batch_size=1024,
                                     print_extra_func=None, snapshot_path=None, epochs_run=0)
+        # MI355X-side option (no counterpart in the reference): forward + loss + backward of a step replayed from ONE HIP graph
+        # (graphs.GraphedTrainStep) -- for the launch-bound small lattices; same numbers as the eager step
+        self.graphed = False
+        self._graph_step = None
 
     def __call__(self, n_epochs=1000, save_every=None, batch_size=64, optimizer_class=torch.optim.AdamW,
-                 scheduler=None, loss_fn=None, hyperparam={}, checkpoint_dict={}):
+                 scheduler=None, loss_fn=None, hyperparam={}, checkpoint_dict={}, graphed=None):
+        if graphed is not None:
+            self.graphed = bool(graphed)
         self.hyperparam.update(hyperparam)
         self.checkpoint_dict.update(checkpoint_dict)
         self._maybe_resume()
@@ -133,17 +139,28 @@ class Fitter:
         """Draw, push through the flow, evaluate the loss, backpropagate, update."""
         model = self._model
         x, logr = model.prior.sample_(self.train_batch_size)
-        y, logJ = model.net_(x)
-        logq, logp = logr - logJ, -model.action(y)
-        loss = self.loss_fn(logq, logp)
-        self.optimizer.zero_grad()
-        loss.backward()
+        if self.graphed and x.is_cuda:
+            loss, logqp = self._graphed_step(x, logr)
+            logq, logp = logqp, 0
+        else:
+            y, logJ = model.net_(x)
+            logq, logp = logr - logJ, -model.action(y)
+            loss = self.loss_fn(logq, logp)
+            self.optimizer.zero_grad()
+            loss.backward()
         model.device_handler.all_reduce_gradients()
         if bool(torch.isnan(loss)):
             print("OOPS: loss is divergent -> no *step* is taken.")
         else:
             self.optimizer.step()
         return loss, logq - logp
+
+    def _graphed_step(self, x, logr):
+        key = (self.train_batch_size, self.loss_fn, tuple(x.shape), x.dtype)
+        if self._graph_step is None or self._graph_step[0] != key:
+            from .graphs import GraphedTrainStep
+            self._graph_step = (key, GraphedTrainStep(self._model, self.loss_fn, self.train_batch_size))
+        return self._graph_step[1](x, logr)
 
     def checkpoint(self, epoch, loss, save_every):
         handler, opts = self._model.device_handler, self.checkpoint_dict

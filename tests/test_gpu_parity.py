@@ -2374,3 +2374,125 @@ def test_small_lattice_kernel_edge_cases():
         cpu0 = torch.zeros((1,) + shape, device='cpu', dtype=torch.float32)
         _hip.small_lattice_coupling(0, cpu0, cpu0, packed, biases, None, 0, cout, acts,
                                     _hip.make_rqs_opts(m, (-4, 4), (-4, 4), lim["extrap"], _hip.LAYOUT_PAIR), False)
+
+
+@pytest.mark.parametrize("shape,kinds,B", [((16, 16), ['affine'] * 2 + ['rqs'], 32), ((6, 8, 16), ['rqs'] * 2, 8),
+                                            ((2, 2, 4, 32), ['rqs', 'affine'], 4)])
+def test_graphed_train_step_equals_the_eager_step(shape, kinds, B):
+    """GraphedTrainStep (forward + reverse-KL loss + backward of Fitter.step, reference src/_normflowcore.py:275-294, replayed
+    from one HIP graph) against the eager step on the same draws: loss, log q/p and every parameter's gradient bit for bit,
+    also AFTER optimiser steps (the weight repacking is part of the graph: a replay must use the current values), and through
+    the guard that re-captures when a weight leaves the range the split-fp16 kernels were validated for."""
+    import normflow__amd as nf
+    from normflow__amd.prior import NormalPrior
+    from normflow__amd.action import ScalarPhi4Action
+    from normflow__amd.fitter import kl_mean
+    torch.manual_seed(11)
+    mask = EvenOddMask(shape=shape)
+    lim = dict(xlim=(-5.0, 5.0), ylim=(-5.0, 5.0), extrap={'left': 'linear', 'right': 'linear'})
+    mk = lambda c: ConvAct(1, c, 3, conv_dim=len(shape), hidden_sizes=[8, 8], acts=['tanh', 'tanh', None])
+    net_ = ModuleList_([RQSplineCoupling_([mk(46)], mask=mask, **lim) if k == 'rqs' else AffineCoupling_([mk(2)], mask=mask)
+                        for k in kinds])
+    net_.to(device=DEV, dtype=torch.float32)
+    prior = NormalPrior(loc=torch.zeros(shape, device=DEV, dtype=torch.float32),
+                        scale=torch.ones(shape, device=DEV, dtype=torch.float32))
+    model = nf.Model(net_=net_, prior=prior, action=ScalarPhi4Action(kappa=0.67, m_sq=-4 * 0.67, lambd=0.5))
+    params = list(net_.parameters())
+    opt = torch.optim.Adam(params, lr=1e-2)
+
+    def eager(x, logr):
+        for p in params:
+            p.grad = None
+        y, logj = net_(x)
+        logq, logp = logr - logj, -model.action(y)
+        loss = kl_mean(logq, logp)
+        loss.backward()
+        return loss.detach().clone(), (logq - logp).detach().clone(), [p.grad.clone() for p in params]
+
+    state = torch.cuda.get_rng_state(DEV)
+    step = nf.GraphedTrainStep(model, kl_mean, B)
+    assert torch.equal(state, torch.cuda.get_rng_state(DEV))        # the capture's example draw left the stream alone
+    for it in range(4):
+        x, logr = prior.sample_(B)
+        if it == 3:                                                   # outside the validated range: the guard re-captures
+            with torch.no_grad():
+                params[0].view(-1)[0] = 40.0
+        with _hip.options(split16=it < 3):                            # (the re-captured graph runs the exact fp32 kernels)
+            l0, d0, g0 = eager(x, logr)
+        l1, d1 = step(x, logr)
+        assert torch.equal(l0, l1) and torch.equal(d0, d1), (it, float(l0), float(l1))
+        for p, g in zip(params, g0):
+            if it < 3 or len(shape) < 4:
+                assert torch.equal(p.grad, g), (it, float((p.grad - g).abs().max()))
+            else:           # (4-D layers off the split-fp16 chain: nf_conv_wgrad adds its partial sums with float atomics)
+                assert float((p.grad - g).abs().max()) <= 1e-5 * float(g.abs().max()), it
+        opt.step()
+    with pytest.raises(ValueError):
+        step(torch.zeros((B + 1,) + shape, device=DEV, dtype=torch.float32), torch.zeros(B + 1, device=DEV, dtype=torch.float32))
+
+
+def test_fit_graphed_reproduces_the_eager_loss_history():
+    """model.fit(..., graphed=True) == model.fit(...) epoch by epoch (same seed): the option changes how a step is launched,
+    not what it computes."""
+    import copy
+    import normflow__amd as nf
+    from normflow__amd.prior import NormalPrior
+    from normflow__amd.action import ScalarPhi4Action
+    shape = (8, 8)
+    mask = EvenOddMask(shape=shape)
+    mk = lambda c: ConvAct(1, c, 3, conv_dim=2, hidden_sizes=[8, 8], acts=['tanh', 'tanh', None])
+    torch.manual_seed(4)
+    net0 = ModuleList_([AffineCoupling_([mk(2)], mask=mask), RQSplineCoupling_([mk(22)], mask=mask, xlim=(-5, 5), ylim=(-5, 5),
+                                                                              extrap={'left': 'linear', 'right': 'linear'})])
+    hist = []
+    for graphed in (False, True):
+        net_ = copy.deepcopy(net0)
+        net_.to(device=DEV, dtype=torch.float32)
+        prior = NormalPrior(loc=torch.zeros(shape, device=DEV, dtype=torch.float32),
+                            scale=torch.ones(shape, device=DEV, dtype=torch.float32))
+        model = nf.Model(net_=net_, prior=prior, action=ScalarPhi4Action(kappa=0.67, m_sq=-4 * 0.67, lambd=0.5))
+        torch.manual_seed(9)
+        model.fit(n_epochs=12, batch_size=64, hyperparam=dict(lr=0.01), checkpoint_dict=dict(print_stride=1000), graphed=graphed)
+        hist.append(list(model.fit.train_history['loss']))
+    assert hist[0] == hist[1], (hist[0][-3:], hist[1][-3:])
+
+
+@pytest.mark.parametrize("lattice,cin,cout,B", [((16, 16, 16), 8, 46, 160), ((16, 16, 16), 8, 8, 160), ((16, 16, 16), 1, 8, 33),
+                                                ((16, 16), 8, 2, 512), ((12, 10), 8, 22, 7), ((6, 6, 10), 3, 46, 5)])
+def test_conv_wgrad_sites_kernel_vs_autograd(lattice, cin, cout, B):
+    """nf_conv_wgrad_sites (few-column layers: the waves split the sites; pair-compact cotangents walked at their active sites
+    only; fixed-order sums) against autograd through a circular fp64 convolution (torch, the definition the oracle's
+    circular_conv_direct restates; reference: src/nn/scalar/convNd.py:86-126 differentiated by src/_normflowcore.py:288):
+    full and pair-compact cotangents of both parities, more items than workgroups, non-power-of-two lattices, and the
+    same bits on a second run."""
+    import torch.nn.functional as F
+    d = len(lattice)
+    g = torch.Generator(device='cpu').manual_seed(B + cout)
+    x = torch.randn((B, cin) + lattice, generator=g, dtype=torch.float32, device='cpu').to(DEV)
+    gz = torch.randn((B, cout) + lattice, generator=g, dtype=torch.float32, device='cpu').to(DEV)
+    conv = {1: F.conv1d, 2: F.conv2d, 3: F.conv3d}[d]
+    w = torch.zeros((cout, cin) + (3,) * d, dtype=torch.float64, device=DEV, requires_grad=True)
+    bias = torch.zeros(cout, dtype=torch.float64, device=DEV, requires_grad=True)
+    out = conv(F.pad(x.double(), (1, 1) * d, mode='circular'), w, bias)
+    V = x[0, 0].numel()
+    coords = torch.stack(torch.meshgrid(*[torch.arange(n, device=DEV) for n in lattice], indexing='ij')).sum(0)
+    for parity in (-1, 0, 1):
+        if parity < 0:
+            cot, gzk = gz, gz
+        else:
+            act = (coords % 2 == parity)
+            cot = gz * act
+            gzk = gz.reshape(B, cout, V)[:, :, act.reshape(-1)].contiguous()      # pair-compact: the active site of every pair
+        gw0, gb0 = torch.autograd.grad(out, (w, bias), cot.double(), retain_graph=True)
+        got = _hip.conv_weight_grad(x, gzk, (3,) * d, None, parity)
+        assert got is not None
+        gw, gb = got
+        scale = float(gw0.abs().max())
+        assert float((gw.double() - gw0).abs().max()) <= 2e-5 * scale, (parity, float((gw.double() - gw0).abs().max()), scale)
+        assert float((gb.double() - gb0).abs().max()) <= 2e-5 * max(1.0, float(gb0.abs().max()))
+        gw2, gb2 = _hip.conv_weight_grad(x, gzk, (3,) * d, None, parity)
+        assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    if cout <= 8:                                                     # the fp64 instance
+        gw0, gb0 = torch.autograd.grad(out, (w, bias), gz.double())
+        gw, gb = _hip.conv_weight_grad(x.double(), gz.double(), (3,) * d)
+        assert float((gw - gw0).abs().max()) <= 1e-11 * float(gw0.abs().max())
