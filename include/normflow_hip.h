@@ -496,6 +496,10 @@ int nf_conv_last_logits_split16(const void *in, int in_split16, const void *wspl
  * to the full lattice (rows, V), zeros at the sites of the other parity; rows = B * channels; lattice[3] even. */
 int nf_expand_pairs(const void *compact, void *full, int64_t rows, const int32_t *lattice, int parity, int dtype,
                     void *stream);
+/* nf_gather_pad: out[i] = index[i] in [0, nsrc) ? src[index[i]] : 0 for i < n, elements of 2, 4 or 8 bytes moved as bits.
+ * The host side re-arranges a layer's weights into a kernel's fragment layout with it (normflow__amd/_hip.py, _pack_by_gather:
+ * the index map of a layer shape is built once): one launch where the torch expression of the same packing is a dozen. */
+int nf_gather_pad(const void *src, const int32_t *index, void *out, int64_t n, int64_t nsrc, int elem_bytes, void *stream);
 /* nf_conv_wgrad_sites: the same gradient (same gw layout and accumulate-into-gw contract as nf_conv_wgrad) for layers with
  * FEW columns -- taps x cin + 1 <= 224, i.e. every 1-, 2- and 3-D 3-tap layer of up to 8 input channels: the layers of the
  * small lattices flows are usually trained on (reference: src/_normflowcore.py:275-294 differentiating

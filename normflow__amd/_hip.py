@@ -79,6 +79,7 @@ PROTOTYPES = {
     "nf_absmax_bits": (_I, [_P, _I64, _P, _P]),
     "nf_conv_last_logits_split16": (_I, [_P, _I, _P, _P, _P, _I64, C.POINTER(C.c_int32), _I, _P, _P]),
     "nf_expand_pairs": (_I, [_P, _P, _I64, C.POINTER(C.c_int32), _I, _I, _P]),
+    "nf_gather_pad": (_I, [_P, _P, _P, _I64, _I64, _I, _P]),
     "nf_conv_wgrad_sites_supported": (_I, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I]),
     "nf_conv_wgrad_sites_workspace": (_SZ, [C.POINTER(C.c_int32), _I, _I, _I]),
     "nf_conv_wgrad_sites": (_I, [_P, _P, _P, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I, _P, _SZ, _I, _P]),
@@ -825,13 +826,38 @@ def conv_supported(x, weight):
             and 1 <= x.dim() - 2 <= 4)
 
 
-def _conv_launch(x, weight, bias, act, compact, parity, weight_src=None):
+_GATHER_MAPS = {}
+
+
+def _pack_by_gather(weight, build, key):
+    """build(weight) -- a pure re-arrangement of the weights with zero padding (two-site expansion, fragment order, row
+    packing: a dozen small torch kernels) -- as ONE gather: the source index of every output element is found once per layer
+    shape by running `build` on a tensor of element numbers, then every packing is one nf_gather_pad launch.  (A training step
+    re-packs every layer's weights twice, forward and flipped / transposed for the input gradient: on small lattices those
+    launches were a quarter of the step.)"""
+    key = (tuple(weight.shape), weight.device) + key
+    ent = _GATHER_MAPS.get(key)
+    if ent is None:
+        probe = torch.arange(1, weight.numel() + 1, dtype=torch.float64, device=weight.device).reshape(weight.shape)
+        packed = build(probe)
+        idx = (packed.reshape(-1).round().to(torch.int64) - 1).to(torch.int32).contiguous()      # -1: a zero of the padding
+        ent = (idx, tuple(packed.shape))
+        _GATHER_MAPS[key] = ent
+    idx, shape = ent
+    w = weight.contiguous()
+    out = torch.empty(shape, dtype=w.dtype, device=w.device)
+    _check(load().nf_gather_pad(_ptr(w), _ptr(idx), _ptr(out), idx.numel(), w.numel(), w.element_size(), _stream()), "nf_gather_pad")
+    return out
+
+
+def _conv_launch(x, weight, bias, act, compact, parity, weight_src=None, transposed=False):
     """One launch sequence of nf_conv_fwd for a (cout, cin, *k) weight tensor; packs the weights in
-    the fragment layout the library will use (two-site column packing for cout <= 8)."""
+    the fragment layout the library will use (two-site column packing for cout <= 8).  transposed: the layer is the INPUT
+    GRADIENT of the layer with these weights (flipped taps, channels exchanged)."""
     lib = load()
     B, cin = x.shape[:2]
     lat = list(x.shape[2:])
-    cout, ksize = weight.shape[0], list(weight.shape[2:])
+    cout, ksize = weight.shape[1 if transposed else 0], list(weight.shape[2:])
     d = len(lat)
     lat4 = (C.c_int32 * 4)(*([1] * (4 - d) + lat))
     k4 = (C.c_int32 * 4)(*([1] * (4 - d) + ksize))
@@ -842,15 +868,23 @@ def _conv_launch(x, weight, bias, act, compact, parity, weight_src=None):
         return conv_first_split16(x, weight, bias, act, weight_src)
     if split16 and not (lib.nf_conv_two_site(cout, 0, lat[-1], ksize[-1]) and cout == 8 and x.dtype == torch.float32):
         raise NormflowHipError("split-fp16 output needs an fp32 two-site layer with 8 output channels")
-    if lib.nf_conv_two_site(cout, 0 if split16 else int(compact), lat[-1], ksize[-1]):
-        # 16 columns: [0, cout) = the layer at site 2p (taps 0..k3-1), [8, 8+cout) = the same
-        # channels at site 2p+1 (taps 1..k3): one extra tap along the fastest axis
-        w2 = weight.new_zeros((16, cin) + tuple(ksize[:-1]) + (ksize[-1] + 1,))
-        w2[:cout, ..., :ksize[-1]] = weight
-        w2[8:8 + cout, ..., 1:] = weight
-        wfrag = conv_weight_for_layer(w2, lat4, k4, cin, cout, False if split16 else compact, False, _dtype_code(x))
-    else:
-        wfrag = conv_weight_for_layer(weight, lat4, k4, cin, cout, compact, False, _dtype_code(x))
+    two_site = bool(lib.nf_conv_two_site(cout, 0 if split16 else int(compact), lat[-1], ksize[-1]))
+    eff_compact = False if (two_site and split16) else compact
+
+    def build(w):
+        """the layer's weights (or its flipped / transposed weights: the input gradient's) in the library's fragment layout"""
+        if transposed:
+            w = w.flip(list(range(2, w.dim()))).transpose(0, 1)
+        if two_site:
+            # 16 columns: [0, cout) = the layer at site 2p (taps 0..k3-1), [8, 8+cout) = the same
+            # channels at site 2p+1 (taps 1..k3): one extra tap along the fastest axis
+            w2 = w.new_zeros((16, cin) + tuple(ksize[:-1]) + (ksize[-1] + 1,))
+            w2[:cout, ..., :ksize[-1]] = w
+            w2[8:8 + cout, ..., 1:] = w
+            w = w2
+        return conv_weight_for_layer(w, lat4, k4, cin, cout, eff_compact, False, _dtype_code(x))
+
+    wfrag = _pack_by_gather(weight, build, (transposed, two_site, tuple(lat4), tuple(k4), cin, cout, int(eff_compact), _dtype_code(x)))
     V = 1
     for n in lat:
         V *= n
@@ -1069,14 +1103,15 @@ class ConvFn(torch.autograd.Function):
         bits = absmax_bits(gz) if split_ok else None
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         kdims = list(range(2, weight.dim()))
-        wt = weight.detach().flip(kdims).transpose(0, 1).contiguous() if ctx.needs_input_grad[0] else None
+        # the input gradient's weights (flipped taps, channels exchanged), made when a kernel needs them as a tensor
+        wt = (lambda: weight.detach().flip(kdims).transpose(0, 1).contiguous()) if ctx.needs_input_grad[0] else None
         gx = gw = gb = None
         if ctx.compact:
             # the pair-compact cotangent as it is: the split-fp16 kernels and the few-column weight-gradient kernel read that
             # form, no expanded copy
             gzc = gz.reshape(x.shape[0], weight.shape[0], -1).contiguous()
             if wt is not None and split_ok:
-                gx = conv_input_grad_split16(gzc, wt, bits, ctx.parity, lattice, weight)
+                gx = conv_input_grad_split16(gzc, wt(), bits, ctx.parity, lattice, weight)
             if want_w:
                 got = conv_weight_grad(x, gzc, weight.shape[2:], bits, ctx.parity)
                 if got is not None:
@@ -1087,9 +1122,9 @@ class ConvFn(torch.autograd.Function):
                 gz = _compact_to_full(gz, lattice, ctx.parity)
             gz = gz.reshape((x.shape[0], weight.shape[0]) + lattice).contiguous()
             if wt is not None and gx is None:
-                gx = conv_input_grad_split16(gz, wt, bits, weight=weight)
+                gx = conv_input_grad_split16(gz, wt(), bits, weight=weight) if split_ok else None
                 if gx is None:
-                    gx = _conv_launch(gz, wt, None, 0, False, 0)
+                    gx = _conv_launch(gz, weight.detach(), None, 0, False, 0, transposed=True)
             if want_w and gw is None:
                 gw, gb = conv_weight_grad(x, gz, weight.shape[2:], bits)
         if not ctx.has_bias:

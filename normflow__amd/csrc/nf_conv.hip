@@ -1398,6 +1398,34 @@ extern "C" int nf_conv_wgrad_sites(const void *in, const void *gz, void *gw, int
   return NF_EINVAL;
 }
 
+// out[i] = index[i] < nsrc ? src[index[i]] : 0 -- a weight tensor re-arranged into a kernel's fragment layout (two-site
+// expansion, fragment order, zero padding) in one launch; the index map is built once per layer shape on the host side
+namespace nf {
+template <typename T>
+__global__ __launch_bounds__(256) void gather_pad_kernel(const T *__restrict__ src, const int32_t *__restrict__ index, T *__restrict__ out,
+                                                         int64_t n, int64_t nsrc) {
+  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t k = index[i];
+  out[i] = k >= 0 && k < nsrc ? src[k] : T(0);
+}
+}  // namespace nf
+
+extern "C" int nf_gather_pad(const void *src, const int32_t *index, void *out, int64_t n, int64_t nsrc, int elem_bytes, void *stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  NF_REQUIRE(src && index && out && n >= 0 && nsrc >= 0, "nf_gather_pad: bad arguments");
+  NF_REQUIRE(elem_bytes == 2 || elem_bytes == 4 || elem_bytes == 8, "nf_gather_pad: elements of 2, 4 or 8 bytes");
+  if (n == 0) return NF_OK;
+  const dim3 grid(unsigned((n + 255) / 256));
+  if (elem_bytes == 4)
+    hipLaunchKernelGGL((gather_pad_kernel<uint32_t>), grid, dim3(256), 0, s, static_cast<const uint32_t *>(src), index, static_cast<uint32_t *>(out), n, nsrc);
+  else if (elem_bytes == 8)
+    hipLaunchKernelGGL((gather_pad_kernel<uint64_t>), grid, dim3(256), 0, s, static_cast<const uint64_t *>(src), index, static_cast<uint64_t *>(out), n, nsrc);
+  else
+    hipLaunchKernelGGL((gather_pad_kernel<uint16_t>), grid, dim3(256), 0, s, static_cast<const uint16_t *>(src), index, static_cast<uint16_t *>(out), n, nsrc);
+  return check_launch("gather kernel");
+}
+
 extern "C" int nf_act_vjp(const void *grad_out, const void *y, void *grad_pre, int64_t n, int act, int dtype,
                           void *stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
