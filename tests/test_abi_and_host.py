@@ -448,3 +448,47 @@ def test_small3d_weight_packers_match_the_documented_fragments():
                         want3[t, i, lane] = w3.reshape(40, 8, 27)[ch, :, k]
     for got, want in ((r1, want1), (r2, want2), (r3, want3)):
         assert float((got - want).abs().max()) <= 2e-7 * max(1.0, float(want.abs().max()))      # hi + lo carries 22 bits
+
+
+def test_training_entry_points_of_the_small_lattices_validate_without_gpu():
+    """nf_conv_wgrad_sites (+ _supported, _workspace) and nf_gather_pad: which layers they take, and that bad arguments come
+    back as a status code with a message before any launch."""
+    lib = _hip.load()
+    err = lambda: lib.nf_last_error_string().decode()
+    i4 = lambda *l: (ctypes.c_int32 * 4)(*l)
+    F32, F64 = _hip.NF_F32, _hip.NF_F64
+    assert lib.nf_conv_wgrad_sites_supported(i4(1, 16, 16, 16), i4(1, 3, 3, 3), 8, 46, F32) == 1       # config 3's last layer
+    assert lib.nf_conv_wgrad_sites_supported(i4(1, 1, 16, 16), i4(1, 1, 3, 3), 8, 2, F64) == 1         # config 2, fp64
+    assert lib.nf_conv_wgrad_sites_supported(i4(1, 1, 1, 10), i4(1, 1, 1, 3), 3, 5, F32) == 1
+    assert lib.nf_conv_wgrad_sites_supported(i4(4, 4, 4, 32), i4(3, 3, 3, 3), 1, 8, F32) == 1          # 81 + 1 columns
+    assert lib.nf_conv_wgrad_sites_supported(i4(4, 4, 4, 32), i4(3, 3, 3, 3), 8, 8, F32) == 0          # 649 columns: nf_conv_wgrad(_split16)
+    assert lib.nf_conv_wgrad_sites_supported(i4(1, 16, 16, 16), i4(1, 3, 3, 3), 8, 46, F64) == 0       # fp64: 3 x 14 tiles do not fit
+    assert lib.nf_conv_wgrad_sites_supported(i4(1, 16, 16, 16), i4(1, 3, 3, 3), 8, 49, F32) == 0
+    assert lib.nf_conv_wgrad_sites_supported(i4(1, 16, 16, 16), i4(1, 3, 2, 3), 8, 8, F32) == 0        # even kernel extent
+    need = lib.nf_conv_wgrad_sites_workspace(i4(1, 3, 3, 3), 8, 46, F32)
+    assert need == 512 * 48 * 224 * 4
+    rc = lib.nf_conv_wgrad_sites(None, None, None, 1, i4(1, 16, 16, 16), i4(1, 3, 3, 3), 8, 46, -1, None, 0, F32, None)
+    assert rc == -1 and "NULL" in err()
+    rc = lib.nf_conv_wgrad_sites(None, None, None, 1, i4(4, 4, 4, 32), i4(3, 3, 3, 3), 8, 8, -1, None, 0, F32, None)
+    assert rc == -1 and "not supported" in err()
+    assert lib.nf_gather_pad(None, None, None, 4, 4, 4, None) == -1 and "bad arguments" in err()
+    one = (ctypes.c_int32 * 1)(0)
+    assert lib.nf_gather_pad(one, one, one, 1, 1, 3, None) == -1 and "2, 4 or 8 bytes" in err()
+    assert lib.nf_gather_pad(one, one, one, 0, 1, 4, None) == 0
+
+
+def test_graphed_train_step_refuses_cpu_models():
+    """GraphedTrainStep is a HIP-graph facility: a CPU model is refused with a message, Fitter.graphed is off by default and
+    ignored for CPU tensors (the eager step runs)."""
+    import normflow__amd as nf
+    from normflow__amd.prior import NormalPrior
+    from normflow__amd.action import ScalarPhi4Action
+    from normflow__amd.nn import DistConvertor_, ModuleList_
+    from normflow__amd.fitter import kl_mean
+    with torch.device("cpu"):
+        net_ = ModuleList_([DistConvertor_(6, symmetric=True)])
+        prior = NormalPrior(loc=torch.zeros(1), scale=torch.ones(1))
+        model = nf.Model(net_=net_, prior=prior, action=ScalarPhi4Action(kappa=0, m_sq=-1.2, lambd=0.5))
+    assert model.fit.graphed is False
+    with pytest.raises(ValueError, match="CUDA/HIP"):
+        nf.GraphedTrainStep(model, kl_mean, 8)
