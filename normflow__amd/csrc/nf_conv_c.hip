@@ -238,6 +238,7 @@ __global__ __launch_bounds__(512, 2) void conv_c2_kernel(ConvArgs A) {
           const int j2 = rj2[sl][h];
           fbase[sl][h] = (j2 == 0 ? poff[0] : (j2 == 1 ? poff[1] : poff[2])) + roff[sl][h];
         }
+      __builtin_amdgcn_s_setprio(2);           // four waves share a SIMD: the one that multiplies issues first
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         if (tz[t] < NT) {
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(512, 2) void conv_c2_kernel(ConvArgs A) {
           }
         }
       }
+      __builtin_amdgcn_s_setprio(0);
     }
     // (2) entry e + 3 (loaded an iteration ago) goes into the ring slot nobody reads; the loads of entry e + 4 are issued
     if (stage_live) {
@@ -273,6 +275,7 @@ __global__ __launch_bounds__(512, 2) void conv_c2_kernel(ConvArgs A) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         if (tz[t] < NT) {
+          // (the packed forms v_pk_add_f32 / v_pk_fma_f32 / v_cvt_pk_f16_f32 for two channels at a time were measured: 2 % slower)
           f16x4 hi, lo;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {

@@ -53,6 +53,9 @@ struct Geo {
   static constexpr int LDS_BYTES = RING + 2 * XBUF;         // 147456 / 155648 <= 163840
   static_assert(LDS_BYTES <= 160 * 1024, "ring + exchange must fit the CU's LDS");
 };
+#ifndef NF_G2_PRIO
+#define NF_G2_PRIO 1
+#endif
 constexpr int NSA = 14;                       // slices of the A waves (0..13); B waves: 14..26
 constexpr float kInvWScale = 1.0f / 1024.0f;  // the weights are packed scaled by 2^10 (normflow__amd/_hip.py: SPLIT16_WEIGHT_SCALE)
 }  // namespace g2
@@ -356,6 +359,9 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
     if (isB && have_prev && !(NF_G2_ABL & 2)) epilogue((k - 1) & 1);
     NF_G2TICK(1)      // epilogue (B)
     // (3) my share of the 27 slices, for both tiles
+#if NF_G2_PRIO
+    __builtin_amdgcn_s_setprio(2);             // the wave that multiplies goes first at the SIMD's issue port
+#endif
     f32x4 am[2], ac[2];                        // per tile: hi*hi sums, and the two correction products
     am[0] = am[1] = ac[0] = ac[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     unsigned rowa[4], rowl[4];                 // LDS offset of this lane's fragment (hi, lo) in ring plane (rbase + i), combo (0, 0)
@@ -443,6 +449,9 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
       dma_slot(3);
     }
 #undef NF_SB
+#if NF_G2_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (!isB && have_prev && !(NF_G2_ABL & 2)) epilogue((k - 1) & 1);
     NF_G2TICK(2)      // fragment reads + MFMAs + DMA pieces (+ the A waves' epilogue)
     // (4) the partial sums of the partner's tile cross over; mine stay for the next step's epilogue
