@@ -364,7 +364,6 @@ __global__ __launch_bounds__(512, 1) void conv_small3d_kernel8(SmallArgs A) {
   unsigned char *H2 = H1 + RING * PB;
   float *pt = reinterpret_cast<float *>(H2 + RING * PB) + w4 * (48 * PTS);
   double *red = reinterpret_cast<double *>(H2 + RING * PB + 4 * PTW);
-  constexpr int NT = KIND == 1 ? 1 : 3;
   const int ntw = (L1 / 2 - w4 + 3) / 4;
   auto wrap1 = [](int v, int L) { return v < 0 ? v + L : (v >= L ? v - L : v); };
   auto ring = [&](int p) { return ((p + 8) & (RING - 1)) * PB; };

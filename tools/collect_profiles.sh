@@ -17,7 +17,7 @@ done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU --kernel-trace --output-format csv -d $P/sq -o run -- python3 tools/kbench.py --reps 2 > $P/sq.log 2>&1
 for f in $P/FETCH_SIZE_k2/*/*counter_collection.csv $P/FETCH_SIZE_k2/*counter_collection.csv; do [ -f "$f" ] && cp $f $P/FETCH_SIZE/k2_counter_collection.csv; done
 for f in $P/WRITE_SIZE_k2/*/*counter_collection.csv $P/WRITE_SIZE_k2/*counter_collection.csv; do [ -f "$f" ] && cp $f $P/WRITE_SIZE/k2_counter_collection.csv; done
-python tools/make_pmc_profile.py --fetch $P/FETCH_SIZE --write $P/WRITE_SIZE --sq $P/sq --out $P/pmc_kernels.json --note "round 3 kernels (conv_c2 / conv_g2 / conv_h as round 2 + run-time knots_len in conv_h); kbench at the pipeline's 256-sample slab; K2 at its 33-sample slab"
+python tools/make_pmc_profile.py --fetch $P/FETCH_SIZE --write $P/WRITE_SIZE --sq $P/sq --out $P/pmc_kernels.json --note "round 3 kernels (conv_c2 / conv_g2 / conv_h as round 2 + run-time knots_len in conv_h, branch-free activations and s_setprio in conv_c2 / conv_g2); kbench at the pipeline's 256-sample slab; K2 at its 33-sample slab"
 python bench.py --steps 3 --warmup 1 --batch 128 --no-cpu-baseline --no-other-configs > $P/bench_batch128.json 2> $P/bench128.err || true
 python tools/config_bench.py > $P/config_bench.txt 2>&1 || true
 python tools/c3_bench.py > $P/c3_bench.txt 2>&1 || true
@@ -29,5 +29,6 @@ done
 python tools/train_bench.py > $P/train_bench.txt 2>&1 || true
 python tools/train_step_profile.py >> $P/train_bench.txt 2>&1 || true
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/traintrace -o run -- python3 tools/train_step_profile.py > $P/traintrace.log 2>&1 || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/trainc3 -o run -- python3 tools/train_prof_c3.py > $P/trainc3.log 2>&1 || true
 find $P -name "*kernel_stats.csv" | head -5
 tail -c 400 $P/bench.json

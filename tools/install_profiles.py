@@ -42,7 +42,8 @@ for src, dst in ((pmc_name, f"{T}_pmc_kernels.json"), ("trace/run_kernel_stats.c
                  ("bench_under_rocprof.json", f"{T}_bench_under_rocprof.json"), ("bench_batch128.json", f"{T}_bench_batch128.json"),
                  ("bench.json", f"{T}_bench.json"), ("config_bench.txt", f"{T}_config_bench.txt"), ("c3_bench.txt", f"{T}_c3_bench.txt"),
                  ("c3trace/run_kernel_stats.csv", f"{T}_c3_kernel_stats.csv"), ("train_bench.txt", f"{T}_train_bench.txt"),
-                 ("traintrace/run_kernel_stats.csv", f"{T}_train_kernel_stats.csv")):
+                 ("traintrace/run_kernel_stats.csv", f"{T}_train_kernel_stats.csv"),
+                 ("trainc3/run_kernel_stats.csv", f"{T}_train_c3_kernel_stats.csv")):
     if os.path.exists(os.path.join(P, src)):
         shutil.copy(os.path.join(P, src), os.path.join(O, dst))
 for d, name in (("c3sq", "c3_pmc_sq"), ("c3FETCH_SIZE", "c3_pmc_fetch_size"), ("c3WRITE_SIZE", "c3_pmc_write_size")):
