@@ -193,39 +193,50 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4;
 
-  // the XCDs take turns: step k of the launch is items [k nb, (k+1) nb), XCD x (= blockIdx & 7) the x-th eighth of them.  With
-  // 2x2x2x32 boxes an XCD then meets its own boxes' neighbours along the slowest axis one step later (measured: 21.9 GB per
-  // 256-sample launch through the fabric; a contiguous eighth of the items per XCD, which is better for K5g's boxes: 30.4 GB)
-  const int nb = gridDim.x;
-  const int vb = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
-  if (vb >= A.nitems) return;
-  const int n_my = int((A.nitems - vb + nb - 1) / nb);
-  auto decode = [&](int it, int &b, int (&o)[4]) {
-    b = it / A.nboxes;
-    int bid = it - b * A.nboxes;
+  // Item order (round 3).  An item = (sample, box); boxes of a sample are numbered [tile of 4 x 4 (4 x 8 when a row is one segment) boxes in axes 1, 2][box along axis
+  // 0][place in the tile][segment], and every XCD (= blockIdx & 7: workgroups are dealt to the XCDs round-robin) owns a CONTIGUOUS
+  // eighth of the launch's items, its workgroups taking consecutive ones.  The 32 workgroups of an XCD then work on one
+  // compact tile and march along axis 0: three quarters of the halo
+  // rows an item asks for were asked for by a neighbour on the same XCD at the same time or one step earlier (its L2 has
+  // them).  Rounds 1-2 numbered the boxes row-major and dealt every step's 256 items out in eighths, which brought the
+  // neighbour along axis 0 back one step later when a sample has 16 x 16 x 16 boxes of one segment (32^4: 15.3 GB fetched per
+  // 256 samples, 1.8 x the tensor) and never otherwise (48^4: 37.8 GB per 50 samples, 4.4 x: profiles/r03_pmc_lat48_kernels.json).
+  const int nb = gridDim.x, nx = nb >> 3;
+  const int64_t nper = (A.nitems + 7) >> 3;               // items of an XCD's range
+  const int64_t vb = int64_t(blockIdx.x & 7) * nper + (blockIdx.x >> 3);
+  const int64_t vend = (int64_t(blockIdx.x & 7) + 1) * nper < A.nitems ? (int64_t(blockIdx.x & 7) + 1) * nper : A.nitems;
+  if (vb >= vend) return;
+  const int n_my = int((vend - vb + nx - 1) / nx);
+  // mixed radix of a box number, least significant digit last: [T1][T2][n0][t1][t2][ns]
+  // (a tile holds as many items as an XCD has workgroups when it can: 4 x 4 x 2 segments, or 4 x 8 boxes of one segment)
+  const int td1 = (A.nbox[1] & 3) == 0 ? 4 : ((A.nbox[1] & 1) == 0 ? 2 : 1);
+  const int td2 = (A.nbox[3] == 1 && (A.nbox[2] & 7) == 0) ? 8 : ((A.nbox[2] & 3) == 0 ? 4 : ((A.nbox[2] & 1) == 0 ? 2 : 1));
+  const int rad[6] = {A.nbox[1] / td1, A.nbox[2] / td2, A.nbox[0], td1, td2, A.nbox[3]};
+  auto decode = [&](int64_t it, int &b, int (&d)[6]) {
+    b = int(it / A.nboxes);
+    int q = int(it - int64_t(b) * A.nboxes);
 #pragma unroll
-    for (int mu = 3; mu >= 0; --mu) {
-      o[mu] = (bid % A.nbox[mu]) * A.box[mu];
-      bid /= A.nbox[mu];
+    for (int k = 5; k >= 0; --k) {
+      d[k] = q % rad[k];
+      q /= rad[k];
     }
   };
-
-  // the block's items are nb apart: (sample, box coordinates) advance by mixed-radix counters, no divisions
-  int sb_, sc_[4];
-  {
-    int so_[4];
-    decode(nb, sb_, so_);
-#pragma unroll
-    for (int mu = 0; mu < 4; ++mu) sc_[mu] = so_[mu];
-  }
-  auto advance = [&](int &b, int (&o)[4]) {
+  auto coords = [&](const int (&d)[6], int (&o)[4]) {       // box origin in sites (boxes are 2 x 2 x 2 rows x one 32-site segment)
+    o[0] = 2 * d[2];
+    o[1] = 2 * (d[0] * td1 + d[3]);
+    o[2] = 2 * (d[1] * td2 + d[4]);
+    o[3] = SEGW * d[5];
+  };
+  // a workgroup's items are nx apart: (sample, digits) advance by mixed-radix counters, no divisions
+  int sb_, sd_[6];
+  decode(nx, sb_, sd_);
+  auto advance = [&](int &b, int (&d)[6]) {
     int carry = 0;
 #pragma unroll
-    for (int mu = 3; mu >= 0; --mu) {
-      o[mu] += sc_[mu] + carry * A.box[mu];
-      const int lim = A.nbox[mu] * A.box[mu];
-      carry = o[mu] >= lim ? 1 : 0;
-      o[mu] -= carry ? lim : 0;
+    for (int k = 5; k >= 0; --k) {
+      d[k] += sd_[k] + carry;
+      carry = d[k] >= rad[k] ? 1 : 0;
+      d[k] -= carry ? rad[k] : 0;
     }
     b += sb_ + carry;
   };
@@ -610,8 +621,9 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   };
 
   int pb = 0, po[4] = {0, 0, 0, 0};            // the item whose logits sit in pt
-  int cb, co4[4];
-  decode(vb, cb, co4);
+  int cb, co4[4], n1d[6];
+  decode(vb, cb, n1d);
+  coords(n1d, co4);
   if (!pre) stage(cb, co4, smem_h);            // (pre-split input: by LDS-DMA below, once its helpers exist)
   // Pre-split input (the pipeline's path): the next item's image is brought in by LDS-DMA, one halo row = one 1 KiB piece =
   // one wave-instruction (the pair tensor's rows ARE the image rows): no staging registers, no ds_write -- the mover's 128
@@ -681,7 +693,10 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     wait_vm<0>();
   }
   int n1b = cb, n1o[4] = {co4[0], co4[1], co4[2], co4[3]};      // item m + 1
-  if (n_my > 1) advance(n1b, n1o);
+  if (n_my > 1) {
+    advance(n1b, n1d);
+    coords(n1d, n1o);
+  }
   if (FUSE != 3) prefetch_x(cb, co4);
   lds_barrier();                                // P: image 0 ready
   // n_my + 1 rounds, the last one only the epilogue of the last item: ONE copy of the epilogue in the code, so that every
@@ -689,7 +704,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   // separately inlined copy behind the loop the compiler is free to contract a * b + c differently in the two, and the last
   // bit of log|J| then depends on the batch order: seen in an experiment of round 2)
   for (int m = 0; m <= n_my; ++m) {
-    if (m > 0 && !NF_DBG(A, 128)) epilogue(pb, po, int64_t(vb) + int64_t(m - 1) * nb);     // dbg 128: timing ablation
+    if (m > 0 && !NF_DBG(A, 128)) epilogue(pb, po, vb + int64_t(m - 1) * nx);     // dbg 128: timing ablation
     if (m == n_my) break;
     if (FUSE != 3) prefetch_x(cb, co4);         // for the epilogue of item m, one iteration from now
     // image m+1 goes where image m-1 and then the partial sums of item m-1 were: after the epilogue above, all rows ahead of
@@ -710,7 +725,10 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     cb = n1b;
 #pragma unroll
     for (int mu = 0; mu < 4; ++mu) { po[mu] = co4[mu]; co4[mu] = n1o[mu]; }
-    if (m + 2 < n_my) advance(n1b, n1o);
+    if (m + 2 < n_my) {
+      advance(n1b, n1d);
+      coords(n1d, n1o);
+    }
     lds_barrier();                              // B2: the partial sums of item m are in pt and in image m
     if (pre) wait_vm<0>();                      // image m+1 has landed (a whole MFMA phase after its first row was issued)
     lds_barrier();                              // Bs: the compute waves have added them up: logits of item m in pt

@@ -16,6 +16,7 @@ ap.add_argument("--k2-slab", type=int, default=33)
 ap.add_argument("--min-ms", type=float, default=0.3)
 ap.add_argument("--out", required=True)
 ap.add_argument("--note", default="")
+ap.add_argument("--lattice", default="32,32,32,32")
 a = ap.parse_args()
 
 
@@ -60,7 +61,7 @@ for k in sorted(set(fetch) | set(write)):
         if "SQ_LDS_IDX_ACTIVE" in s and "GRBM_GUI_ACTIVE" in s:
             e["lds_busy_fraction"] = s["SQ_LDS_IDX_ACTIVE"] / 256.0 / (s["GRBM_GUI_ACTIVE"] / 8.0)
     kernels[k] = e
-res = {"kernel_src_sha": bench.kernel_src_sha(), "lattice": [32, 32, 32, 32], "knots": 16, "slab_batch": a.slab,
+res = {"kernel_src_sha": bench.kernel_src_sha(), "lattice": [int(t) for t in a.lattice.split(",")], "knots": 16, "slab_batch": a.slab,
        "collection": "rocprofv3 --pmc <one pass per counter set> --kernel-trace --output-format csv -- python3 tools/kbench.py; "
                      "FETCH_SIZE x 1024 x 2 (gfx950: 128-B requests tallied at 64 B), WRITE_SIZE x 1024; means over the full-size launches",
        "note": a.note, "kernels": kernels}
