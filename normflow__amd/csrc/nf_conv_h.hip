@@ -193,56 +193,93 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4;
 
-  // Item order (round 3).  An item = (sample, box); boxes of a sample are numbered [tile of 4 x 4 (4 x 8 when a row is one segment) boxes in axes 1, 2][box along axis
-  // 0][place in the tile][segment], and every XCD (= blockIdx & 7: workgroups are dealt to the XCDs round-robin) owns a CONTIGUOUS
-  // eighth of the launch's items, its workgroups taking consecutive ones.  The 32 workgroups of an XCD then work on one
-  // compact tile and march along axis 0: three quarters of the halo
-  // rows an item asks for were asked for by a neighbour on the same XCD at the same time or one step earlier (its L2 has
-  // them).  Rounds 1-2 numbered the boxes row-major and dealt every step's 256 items out in eighths, which brought the
-  // neighbour along axis 0 back one step later when a sample has 16 x 16 x 16 boxes of one segment (32^4: 15.3 GB fetched per
-  // 256 samples, 1.8 x the tensor) and never otherwise (48^4: 37.8 GB per 50 samples, 4.4 x: profiles/r03_pmc_lat48_kernels.json).
+  // Item order (round 3).  An item = (sample, box, segment).  Every XCD (= blockIdx & 7: workgroups are dealt to the XCDs round-robin)
+  // owns a CONTIGUOUS eighth of the launch's (sample, box) pairs -- boxes of a sample numbered [tile of 4 x 4 (4 x 8 when a row is
+  // one segment) boxes in axes 1, 2][box along axis 0][place in the tile] -- and goes through it once per segment, its workgroups
+  // taking consecutive ones.  The 32 workgroups of an XCD then work on one compact tile and march it along axis 0: three
+  // quarters of the halo rows an item asks for were asked for by a neighbour on the same XCD at the same time or one step
+  // earlier (its L2 has them).  Rounds 1-2 numbered the boxes row-major and dealt every step's 256 items out in eighths, which
+  // brought the neighbour along axis 0 back one step later when a sample has 16 x 16 x 16 boxes of one segment (32^4: 15.3 GB
+  // fetched per 256 samples, 1.8 x the tensor) and never otherwise (48^4: 37.8 GB per 50 samples, 4.4 x).  Segment by segment
+  // rather than segment-fastest: a workgroup's consecutive items are then of one kind (full or half, below), and the phases
+  // of the mover and of the multiplying waves stay matched.
   const int nb = gridDim.x, nx = nb >> 3;
-  const int64_t nper = (A.nitems + 7) >> 3;               // items of an XCD's range
-  const int64_t vb = int64_t(blockIdx.x & 7) * nper + (blockIdx.x >> 3);
-  const int64_t vend = (int64_t(blockIdx.x & 7) + 1) * nper < A.nitems ? (int64_t(blockIdx.x & 7) + 1) * nper : A.nitems;
-  if (vb >= vend) return;
-  const int n_my = int((vend - vb + nx - 1) / nx);
-  // mixed radix of a box number, least significant digit last: [T1][T2][n0][t1][t2][ns]
-  // (a tile holds as many items as an XCD has workgroups when it can: 4 x 4 x 2 segments, or 4 x 8 boxes of one segment)
+  const int nsg = SEGM ? A.nbox[3] : 1;                     // (all counts below fit 31 bits: the launcher checks nitems)
+  const int nbs = A.nboxes / nsg;                           // boxes of a sample (segments apart)
+  const int nb0 = int(A.nitems) / nsg;                      // ... of the launch
+  const int nper = (nb0 + 7) >> 3;                          // an XCD's share of them
+  const int g0 = int(blockIdx.x & 7) * nper;
+  if (g0 >= nb0) return;
+  const int R = nb0 - g0 < nper ? nb0 - g0 : nper;
+  const int l0 = blockIdx.x >> 3;                           // local item numbers of the XCD: l = segment * R + r, box g0 + r
+  if (l0 >= R * nsg) return;
+  const int n_my = (R * nsg - l0 + nx - 1) / nx;
+  // mixed radix of a box number, least significant digit last: [T1][T2][n0][t1][t2]
   const int td1 = (A.nbox[1] & 3) == 0 ? 4 : ((A.nbox[1] & 1) == 0 ? 2 : 1);
-  const int td2 = (A.nbox[3] == 1 && (A.nbox[2] & 7) == 0) ? 8 : ((A.nbox[2] & 3) == 0 ? 4 : ((A.nbox[2] & 1) == 0 ? 2 : 1));
-  const int rad[6] = {A.nbox[1] / td1, A.nbox[2] / td2, A.nbox[0], td1, td2, A.nbox[3]};
-  auto decode = [&](int64_t it, int &b, int (&d)[6]) {
-    b = int(it / A.nboxes);
-    int q = int(it - int64_t(b) * A.nboxes);
+  const int td2 = (nsg == 1 && (A.nbox[2] & 7) == 0) ? 8 : ((A.nbox[2] & 3) == 0 ? 4 : ((A.nbox[2] & 1) == 0 ? 2 : 1));
+  const int rad[5] = {A.nbox[1] / td1, A.nbox[2] / td2, A.nbox[0], td1, td2};
+  struct Item {
+    int l, seg, b, d[5];
+  };
+  auto decode = [&](int l, Item &it) {
+    it.l = l;
+    it.seg = SEGM ? l / R : 0;
+    const int gl = g0 + (l - it.seg * R);
+    it.b = gl / nbs;
+    int q = gl - it.b * nbs;
 #pragma unroll
-    for (int k = 5; k >= 0; --k) {
-      d[k] = q % rad[k];
+    for (int k = 4; k >= 0; --k) {
+      it.d[k] = q % rad[k];
       q /= rad[k];
     }
   };
-  auto coords = [&](const int (&d)[6], int (&o)[4]) {       // box origin in sites (boxes are 2 x 2 x 2 rows x one 32-site segment)
-    o[0] = 2 * d[2];
-    o[1] = 2 * (d[0] * td1 + d[3]);
-    o[2] = 2 * (d[1] * td2 + d[4]);
-    o[3] = SEGW * d[5];
+  auto coords = [&](const Item &it, int (&o)[4]) {          // box origin in sites (boxes are 2 x 2 x 2 rows x one 32-site segment)
+    o[0] = 2 * it.d[2];
+    o[1] = 2 * (it.d[0] * td1 + it.d[3]);
+    o[2] = 2 * (it.d[1] * td2 + it.d[4]);
+    o[3] = SEGW * it.seg;
   };
-  // a workgroup's items are nx apart: (sample, digits) advance by mixed-radix counters, no divisions
-  int sb_, sd_[6];
-  decode(nx, sb_, sd_);
-  auto advance = [&](int &b, int (&d)[6]) {
+  auto slot_of = [&](const Item &it) {                      // the item's place among the log-det partials: [sample][box][segment]
+    const int q = (((it.d[0] * rad[1] + it.d[1]) * rad[2] + it.d[2]) * rad[3] + it.d[3]) * rad[4] + it.d[4];
+    return int64_t(it.b) * A.nboxes + int64_t(q) * nsg + it.seg;
+  };
+  // a workgroup's items are nx apart: (sample, digits) advance by mixed-radix counters, no divisions -- but for the (rare) step
+  // into the next segment, which goes back to the start of the XCD's range
+  int sb_ = nx / nbs, sd_[5];
+  {
+    int q = nx - sb_ * nbs;
+#pragma unroll
+    for (int k = 4; k >= 0; --k) {
+      sd_[k] = q % rad[k];
+      q /= rad[k];
+    }
+  }
+  auto advance = [&](Item &it) {
+    const int ln = it.l + nx;
+    if (SEGM && ln - it.seg * R >= R) {
+      decode(ln, it);
+      return;
+    }
+    it.l = ln;
     int carry = 0;
 #pragma unroll
-    for (int k = 5; k >= 0; --k) {
-      d[k] += sd_[k] + carry;
-      carry = d[k] >= rad[k] ? 1 : 0;
-      d[k] -= carry ? rad[k] : 0;
+    for (int k = 4; k >= 0; --k) {
+      it.d[k] += sd_[k] + carry;
+      carry = it.d[k] >= rad[k] ? 1 : 0;
+      it.d[k] -= carry ? rad[k] : 0;
     }
-    b += sb_ + carry;
+    it.b += sb_ + carry;
   };
 
   // the input may come scaled by a power of two (training: activations of unknown range, nf_conv_last_logits_split16)
   const float in_scale = pow2_scale_for(A.gscale_bits), out_scale = kInvWScale / in_scale;
+  // HALF ITEMS (round 3).  When a row is a whole number of segments plus 8 pairs (L3 = 48, 80, ...), the last segment of a box
+  // holds 8 pairs per row: as one site tile per row half of every tile's lanes were padding (48^4 ran at 0.71 of the per-site
+  // rate of 32^4).  Such an item now packs the two rows (z2 = 0, 1) of a (z0, z1) position into ONE site tile -- lanes 0-7 row
+  // z2 = 0, lanes 8-15 row z2 = 1 -- : 4 site tiles, half the MFMAs, half the exchange, one spline pass.  Unit u of its logit
+  // scratch is (T = u >> 4 = 2 z0 + z1, z2 = (u >> 3) & 1, pair 16 (nseg - 1) + (u & 7)).  The image and its staging are as before.
+  const bool has_half = SEGM && (HP & 15) == 8;
+  const int l_half = R * (nsg - 1);                         // local item numbers >= l_half are the last segment's
 
   if (wave < 3) {
     // ============================================================ compute waves: K third `wave` = fastest-axis tap j3
@@ -288,6 +325,15 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
         RG[i] = (((rr / 9) * H1 + (rr / 3) % 3) * H2 + rr % 3) * RBL;
       }
     }
+    int TPm[2] = {0, 0};      // half items: the lane's slot in the MERGED tile of position (z0, z1), by parity of z0 + z1 (lo: + 512)
+    if (SEGM) {
+      const int pm = lane & 7, z2l = (lane >> 3) & 1;
+#pragma unroll
+      for (int e0 = 0; e0 < 2; ++e0) {
+        const int gI = ((A.parity + (e0 ^ z2l)) & 1) + W, ja = pm + (gI >> 1), para = (gI + 1) & 1;      // ja <= 8: inside the main piece
+        TPm[e0] = para * 256 + ja * 16 + z2l * RBL;
+      }
+    }
     // The three partial sums of a column tile: slot 0 (the wave's OWN column tile, w) stays in the accumulators; slots 1 and
     // 2 are stored straight from the accumulator registers (inline asm: hipcc would copy them to VGPRs first) into two
     // planes [channel][unit] laid over the image the item has just consumed (unit = 16 mt + 4g + r: a 16-byte store per
@@ -320,8 +366,37 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     lds_barrier();            // P: the mover has staged the first image
     for (int m = 0; m < n_my; ++m) {
       const int ioff = (m & 1) * ITEM;
+      const bool half = has_half && l0 + m * nx >= l_half;
+      const int ntile = half ? 4 : 8;           // site tiles of the item (their accumulators: acc[0 .. ntile))
       const unsigned char *img[2] = {smem_h + ioff + TP[0], smem_h + ioff + TP[1]};
       const unsigned char *iml[2] = {smem_h + ioff + TL[0], smem_h + ioff + TL[1]};
+      const unsigned char *imgm[2] = {smem_h + ioff + TPm[0], smem_h + ioff + TPm[1]};
+      // half item: quarter-slice qs = (slice i, position T = qs & 3 = 2 z0 + z1): ONE merged tile, 9 MFMAs; accumulators acc[T]
+      auto fetch_h = [&](auto QC) {
+        constexpr int qs = decltype(QC)::value;
+        constexpr int i = qs >> 2, T = qs & 3, q = qs & 1;
+        constexpr int z0 = T >> 1, z1 = T & 1;
+        const int ro = RG[i] + ((z0 * H1 + z1) * H2) * RBL;
+        fa[q][0] = *reinterpret_cast<const f16x8 *>(imgm[(z0 + z1) & 1] + ro);
+        fl[q][0] = *reinterpret_cast<const f16x8 *>(imgm[(z0 + z1) & 1] + 512 + ro);
+      };
+      auto mult_h = [&](auto QC) {
+        constexpr int qs = decltype(QC)::value;
+        constexpr int i = qs >> 2, T = qs & 3, q = qs & 1;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[T][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[q][0], bh[i][n], acc[T][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[T][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[q][0], bl[i][n], acc[T][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[T][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[q][0], bh[i][n], acc[T][n], 0, 0, 0);
+      };
+      [[maybe_unused]] auto step_h = [&](auto QC) {
+        constexpr int qs = decltype(QC)::value;
+        if constexpr (qs + 1 < 28) fetch_h(std::integral_constant<int, qs + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mult_h(QC);
+        __builtin_amdgcn_sched_barrier(0);
+      };
       auto fetch = [&](auto QC) {
         constexpr int qs = decltype(QC)::value;
         constexpr int i = qs >> 2, t0 = (qs & 3) * 2, q = qs & 1;
@@ -370,7 +445,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
 #if NF_H_ABL & 16
             asm volatile("" ::"v"(ad), "a"(val));
 #else
-            asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ad), "a"(val), "n"(mt << 6) : "memory");
+            if (mt < 4 || ntile == 8) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ad), "a"(val), "n"(mt << 6) : "memory");
 #endif
           }
         }
@@ -380,8 +455,13 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
 #pragma unroll
         for (int n = 0; n < 3; ++n) acc[mt][n] = n == 0 ? acc0 : f32x4{0.f, 0.f, 0.f, 0.f};
 #if !(NF_H_ABL & 32)
-      if constexpr (!(NF_H_ABL & 1)) fetch(std::integral_constant<int, 0>{});
-      static_for<0, 28>(step);
+      if (half) {
+        fetch_h(std::integral_constant<int, 0>{});
+        static_for<0, 28>(step_h);
+      } else {
+        if constexpr (!(NF_H_ABL & 1)) fetch(std::integral_constant<int, 0>{});
+        static_for<0, 28>(step);
+      }
 #endif
       asm volatile("s_nop 15\n\ts_nop 3");      // the LDS instructions below read accumulators the compiler does not know they read: let the last MFMA land
       lds_barrier();            // B1: image m is consumed; the mover has read the logits of item m-1
@@ -395,6 +475,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
         lds_f *po = (lds_f *)(smem_h + 2 * ITEM + home);
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
+          if (mt >= 4 && ntile == 4) break;
           const f32x4 s1 = *(const lds_q *)(pa + (mt << 4));
           const f32x4 s2 = *(const lds_q *)(pa + PT / 4 + (mt << 4));
           f32x4 v;
@@ -496,18 +577,36 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       commit(v1, p0 + PB);
     }
   };
+  auto is_half = [&](const int (&o)[4]) { return has_half && o[3] == SEGW * (nsg - 1); };
+  // unit u of the logit scratch -> box row (z0, z1, z2) and pair p of the segment (full item: u = 16 (4 z0 + 2 z1 + z2) + p;
+  // half item: u = 16 (2 z0 + z1) + 8 z2 + p, 64 units)
+  auto unit_row = [&](bool hf, int u, int &z0, int &z1, int &z2, int &p) {
+    const int mt = u >> 4;
+    z0 = hf ? (mt >> 1) & 1 : mt >> 2;
+    z1 = hf ? mt & 1 : (mt >> 1) & 1;
+    z2 = hf ? (u >> 3) & 1 : mt & 1;
+    p = hf ? u & 7 : u & 15;
+  };
   auto pair_of = [&](int b, const int (&o)[4], int pass, bool &ok) {
-    const int u = pass * 64 + lane;
-    const int mt = u >> 4, p3 = (u & 15) + (o[3] >> 1);          // pair of the row: 16 hs + p
-    ok = p3 < HP;                                                 // (a partial last segment has 8 of 16)
-    const int x0 = o[0] + (mt >> 2), x1 = o[1] + ((mt >> 1) & 1), x2 = o[2] + (mt & 1);
+    const bool hf = is_half(o);
+    int z0, z1, z2, p;
+    unit_row(hf, pass * 64 + lane, z0, z1, z2, p);
+    const int p3 = p + (o[3] >> 1);                               // pair of the row: 16 hs + p
+    ok = hf ? pass == 0 : p3 < HP;                                // (a half item has 64 units; without packing a partial segment has 8 of 16)
+    const int x0 = o[0] + z0, x1 = o[1] + z1, x2 = o[2] + z2;
     return int64_t(b) * (A.V / 2) + ((int64_t(x0) * A.L[1] + x1) * A.L[2] + x2) * HP + (ok ? p3 : 0);
+  };
+  auto unit_parity = [&](const int (&o)[4], int u) {             // which site of unit u's pair is the active one
+    int z0, z1, z2, p;
+    unit_row(is_half(o), u, z0, z1, z2, p);
+    return (A.parity + o[0] + z0 + o[1] + z1 + o[2] + z2) & 1;
   };
   float2 xpre[2] = {{0.f, 0.f}, {0.f, 0.f}};     // the x pairs of the item whose logits are (about to be) in pt
   float2 gpre[2] = {{0.f, 0.f}, {0.f, 0.f}};     // FUSE 4 / 5: and the pairs of the value's cotangent
   auto prefetch_x = [&](int b, const int (&o)[4]) {
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
+      if (pass && is_half(o)) break;             // (a half item has one pass of units)
       bool ok;
       const int64_t pr = pair_of(b, o, pass, ok);
       xpre[pass] = load_field_pair(A, pr);
@@ -523,6 +622,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       const int64_t Vh = A.V / 2;
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
+        if (pass && is_half(o)) break;
         const int u = pass * 64 + lane;
         bool pok;
         const int64_t pair = pair_of(b, o, pass, pok);
@@ -550,9 +650,9 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
       const float gl = A.glogj[b];
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {       // (both passes in flight: two independent dependent chains)
+        if (pass && is_half(o)) break;
         const int u = pass * 64 + lane;
-        const int mt = u >> 4;
-        const int offp = (A.parity + o[0] + (mt >> 2) + o[1] + ((mt >> 1) & 1) + o[2] + (mt & 1)) & 1;
+        const int offp = unit_parity(o, u);
         bool pok;
         const int64_t pair = pair_of(b, o, pass, pok);
         const float2 xv = xpre[pass], gv = gpre[pass];
@@ -586,9 +686,9 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     double lacc = 0.0;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
+      if (pass && is_half(o)) break;
       const int u = pass * 64 + lane;
-      const int mt = u >> 4;
-      const int offp = (A.parity + o[0] + (mt >> 2) + o[1] + ((mt >> 1) & 1) + o[2] + (mt & 1)) & 1;
+      const int offp = unit_parity(o, u);
       bool pok;
       const int64_t pair = pair_of(b, o, pass, pok);
       const float2 xv = xpre[pass];
@@ -621,9 +721,13 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   };
 
   int pb = 0, po[4] = {0, 0, 0, 0};            // the item whose logits sit in pt
-  int cb, co4[4], n1d[6];
-  decode(vb, cb, n1d);
-  coords(n1d, co4);
+  int64_t pslot = 0, cslot;                    // ... and its place among the log-det partials
+  int cb, co4[4];
+  Item n1;
+  decode(l0, n1);
+  cb = n1.b;
+  coords(n1, co4);
+  cslot = slot_of(n1);
   if (!pre) stage(cb, co4, smem_h);            // (pre-split input: by LDS-DMA below, once its helpers exist)
   // Pre-split input (the pipeline's path): the next item's image is brought in by LDS-DMA, one halo row = one 1 KiB piece =
   // one wave-instruction (the pair tensor's rows ARE the image rows): no staging registers, no ds_write -- the mover's 128
@@ -634,9 +738,11 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   // 16 scalar bases (z0, z1) and 4 per-lane offsets (z2, with the lane's place in the row folded in) and a row costs
   // nothing but its LDS address and the instruction (4 scalar instructions where a row offset read out of a lane and a
   // 64-bit address built per row were 8).
+  bool dma_half = false;                         // the item being staged is a half item: slots 0 .. 8 of its rows are all it reads
   const unsigned char *dma_ab[H0 * H1];          // uniform
   unsigned dma_v[H2], dma_v2[H2];               // per lane: main piece / (SEGM) the 17th slots, lanes 0..3
   auto dma_open = [&](int b, const int (&o)[4]) {
+    dma_half = is_half(o);
     const unsigned char *base = static_cast<const unsigned char *>(A.in) + int64_t(b) * A.V * 32;
     unsigned lane_d = lane16, lane_d2 = 0;       // per-lane source offsets inside a row of the pair tensor
     if (SEGM) {
@@ -675,6 +781,13 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   };
   auto dma_rows = [&](unsigned buf, auto R0, auto R1) {     // halo rows [R0, R1) -> image buffer at LDS byte address buf
     constexpr int r0 = decltype(R0)::value, r1 = decltype(R1)::value;
+    if (SEGM && dma_half) {
+      if ((lane & 15) <= 8) {
+#pragma unroll
+        for (int i = r0; i < r1; ++i) dma_row(dma_ab[i / H2], dma_v[i % H2], buf + unsigned(i * RBL));
+      }
+      return;
+    }
 #pragma unroll
     for (int i = r0; i < r1; ++i) dma_row(dma_ab[i / H2], dma_v[i % H2], buf + unsigned(i * RBL));
     if (SEGM) {
@@ -693,9 +806,12 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     wait_vm<0>();
   }
   int n1b = cb, n1o[4] = {co4[0], co4[1], co4[2], co4[3]};      // item m + 1
+  int64_t n1slot = cslot;
   if (n_my > 1) {
-    advance(n1b, n1d);
-    coords(n1d, n1o);
+    advance(n1);
+    n1b = n1.b;
+    coords(n1, n1o);
+    n1slot = slot_of(n1);
   }
   if (FUSE != 3) prefetch_x(cb, co4);
   lds_barrier();                                // P: image 0 ready
@@ -704,7 +820,7 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
   // separately inlined copy behind the loop the compiler is free to contract a * b + c differently in the two, and the last
   // bit of log|J| then depends on the batch order: seen in an experiment of round 2)
   for (int m = 0; m <= n_my; ++m) {
-    if (m > 0 && !NF_DBG(A, 128)) epilogue(pb, po, vb + int64_t(m - 1) * nx);     // dbg 128: timing ablation
+    if (m > 0 && !NF_DBG(A, 128)) epilogue(pb, po, pslot);     // dbg 128: timing ablation
     if (m == n_my) break;
     if (FUSE != 3) prefetch_x(cb, co4);         // for the epilogue of item m, one iteration from now
     // image m+1 goes where image m-1 and then the partial sums of item m-1 were: after the epilogue above, all rows ahead of
@@ -723,11 +839,15 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
     if (more && pre) dma_rows(nbuf, IH{}, IN{});
     pb = cb;
     cb = n1b;
+    pslot = cslot;
+    cslot = n1slot;
 #pragma unroll
     for (int mu = 0; mu < 4; ++mu) { po[mu] = co4[mu]; co4[mu] = n1o[mu]; }
     if (m + 2 < n_my) {
-      advance(n1b, n1d);
-      coords(n1d, n1o);
+      advance(n1);
+      n1b = n1.b;
+      coords(n1, n1o);
+      n1slot = slot_of(n1);
     }
     lds_barrier();                              // B2: the partial sums of item m are in pt and in image m
     if (pre) wait_vm<0>();                      // image m+1 has landed (a whole MFMA phase after its first row was issued)
