@@ -20,10 +20,13 @@ from ...lib.spline import RQSpline
 PARAM_SLAB_BYTES = 6 << 30
 # Largest hidden-activation tensor (fp32-equivalent bytes) a fused atom materialises at once: 1024 samples of 32^4 -- two such
 # tensors are alive at a time, 64 of the GPU's 288 GB.  Fewer, longer launches of each kernel: the headline step is 3 % faster
-# with 1024-sample slabs than with 256 (tools/slab_ab.py; same bits).  The budget shrinks to a fifth of the free device memory
-# when that is less, never below HIDDEN_SLAB_FLOOR; a slab never exceeds 2^30 sites (the kernels index sites in 32 bits).
+# with 1024-sample slabs than with 256 (tools/slab_ab.py; same bits).  On a device with less memory the budget is an eighth
+# of its TOTAL memory (a fixed number per device: a budget that followed the free memory changed the slab sizes from pass to
+# pass and with them every allocation), never below HIDDEN_SLAB_FLOOR; a slab never exceeds 2^30 sites (the kernels index
+# sites in 32 bits).
 HIDDEN_SLAB_BYTES = 32 << 30
 HIDDEN_SLAB_FLOOR = 8 << 30
+_DEVICE_TOTAL = {}
 
 
 # Training: an RQ-spline atom whose (B, 3m-2, V/2) logits would exceed this many bytes runs its last layer + spline as ONE
@@ -219,8 +222,10 @@ class Coupling_(Module_, ABC):
         per_sample = hidden * V * 4
         budget = HIDDEN_SLAB_BYTES
         if B * per_sample > HIDDEN_SLAB_FLOOR and budget > HIDDEN_SLAB_FLOOR and v.is_cuda:
-            free, _ = torch.cuda.mem_get_info(v.device)
-            budget = max(HIDDEN_SLAB_FLOOR, min(budget, free // 5))
+            total = _DEVICE_TOTAL.get(v.device)
+            if total is None:
+                total = _DEVICE_TOTAL[v.device] = torch.cuda.get_device_properties(v.device).total_memory
+            budget = max(HIDDEN_SLAB_FLOOR, min(budget, total // 8))
         step = max(1, min(B, budget // max(1, per_sample), (1 << 30) // max(1, V)))
         return [(b0, min(B, b0 + step)) for b0 in range(0, B, step)]
 
