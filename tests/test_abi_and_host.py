@@ -492,3 +492,25 @@ def test_graphed_train_step_refuses_cpu_models():
     assert model.fit.graphed is False
     with pytest.raises(ValueError, match="CUDA/HIP"):
         nf.GraphedTrainStep(model, kl_mean, 8)
+
+
+def test_hidden_slabs_respect_the_budget_and_the_32_bit_site_index():
+    """Coupling_._hidden_slabs: slabs of a fused atom -- the byte budget (1024 samples of 32^4 at hidden width 8), never more than
+    2^30 sites per slab (the kernels index sites in 32 bits: a narrower net must not get a longer slab), whole coverage."""
+    from normflow__amd.nn import AffineCoupling_, ConvAct
+    from normflow__amd.mask import EvenOddMask
+    from normflow__amd.nn.scalar import couplings_
+    with torch.device("cpu"):
+        cpl = AffineCoupling_([ConvAct(1, 2, 3, conv_dim=2, hidden_sizes=[8, 8], acts=['tanh', 'tanh', None])], mask=EvenOddMask(shape=(4, 4)))
+    V = 32 ** 4
+    for B, hidden, want in ((4096, 8, 1024), (4096, 4, 1024), (1000, 8, 1000), (3, 8, 3)):
+        v = torch.empty((B, V), device="meta")
+        slabs = cpl._hidden_slabs(v, hidden)
+        assert slabs[0] == (0, want) and slabs[-1][1] == B
+        assert all(b1 - b0 <= want and (b1 - b0) * V <= 1 << 30 for b0, b1 in slabs)
+        assert [b0 for b0, _ in slabs[1:]] == [b1 for _, b1 in slabs[:-1]]
+    old = couplings_.set_slab_bytes(hidden=8 << 30)
+    try:
+        assert cpl._hidden_slabs(torch.empty((4096, V), device="meta"), 8)[0] == (0, 256)
+    finally:
+        couplings_.set_slab_bytes(*old)
