@@ -49,6 +49,19 @@ class Mask(torch.nn.Module):
     def purify(self, x_chnl, channel):
         return x_chnl * (self._mask if channel == 0 else self._c_mask)
 
+    def same_partition(self, other):
+        """Does `other` split the lattice into the same two channels?  (Compared once per pair of mask objects.)"""
+        if other is self:
+            return True
+        m = getattr(other, '_mask', None)
+        if m is None or type(other) is not type(self) or m.shape != self._mask.shape:
+            return False
+        seen = self.__dict__.setdefault('_same_as', {})
+        key = (id(other), m.data_ptr(), self._mask.data_ptr())
+        if key not in seen:
+            seen[key] = bool(torch.equal(m.to(self._mask.device), self._mask))
+        return seen[key]
+
     # -- kernel-side view
     def activity(self, channel):
         """uint8 tensor over the lattice: 1 where `channel` is the active partition."""

@@ -45,9 +45,41 @@ class Module_(torch.nn.Module):
     npar = property(count_parameters)
 
 
+def _same_partition(a, b):
+    """Do two coupling blocks split the lattice the same way?  (The same mask object, or equal masks: compared once per pair.)"""
+    ma, mb = getattr(a, 'mask', None), getattr(b, 'mask', None)
+    if ma is None or mb is None:
+        return False
+    if ma is mb:
+        return True
+    fn = getattr(ma, 'same_partition', None)
+    return bool(fn(mb)) if fn is not None else False
+
+
 def _run_chain(blocks, method, x, log0):
-    for blk in blocks:
-        x, log0 = getattr(blk, method)(x, log0)
+    """Apply the blocks in order.  Consecutive coupling blocks over the SAME partition hand each other the two parts of the
+    field as they are: `cat` followed by the next block's `split` gives the parts back (their supports are disjoint), and on a
+    lattice field each of the three is a full pass through memory -- with one coupling block per layer (a common way to
+    write a flow; the reference's protocol is unchanged: couplings_.py:54-78) they were ~8 % of a 32^4 inference pass."""
+    blocks = list(blocks)
+    part_method = 'parts_' + method
+    i, n = 0, len(blocks)
+    while i < n:
+        blk = blocks[i]
+        run = getattr(blk, part_method, None)
+        j = i + 1
+        if run is not None:
+            while j < n and getattr(blocks[j], part_method, None) is not None and _same_partition(blk, blocks[j]):
+                j += 1
+        if run is None or j == i + 1:
+            x, log0 = getattr(blk, method)(x, log0)
+            i += 1
+            continue
+        parts = list(blk.mask.split(x))
+        for k in range(i, j):
+            parts, log0 = getattr(blocks[k], part_method)(parts, log0)
+        x = blk.mask.cat(*parts)
+        i = j
     return x, log0
 
 

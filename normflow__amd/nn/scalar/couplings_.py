@@ -84,20 +84,28 @@ class Coupling_(Module_, ABC):
 
     # ---- block level: identical protocol to the reference (couplings_.py:54-78)
     def forward(self, x, log0=0):
-        parts = list(self.mask.split(x))
+        parts, log0 = self.parts_forward(list(self.mask.split(x)), log0)
+        return self.mask.cat(*parts), log0
+
+    def backward(self, x, log0=0):
+        parts, log0 = self.parts_backward(list(self.mask.split(x)), log0)
+        return self.mask.cat(*parts), log0
+
+    # the block on the two parts of the field (`ModuleList_` chains consecutive blocks over one partition through these,
+    # without the cat / split passes in between)
+    def parts_forward(self, parts, log0=0):
         for k, net in enumerate(self.nets):
             p = k % 2
             parts[p], log0 = self.atomic_forward(x_active=parts[p], x_frozen=parts[1 - p],
                                                  parity=p, net=net, log0=log0)
-        return self.mask.cat(*parts), log0
+        return parts, log0
 
-    def backward(self, x, log0=0):
-        parts = list(self.mask.split(x))
+    def parts_backward(self, parts, log0=0):
         for k in reversed(range(len(self.nets))):
             p = k % 2
             parts[p], log0 = self.atomic_backward(x_active=parts[p], x_frozen=parts[1 - p],
                                                   parity=p, net=self.nets[k], log0=log0)
-        return self.mask.cat(*parts), log0
+        return parts, log0
 
     @abstractmethod
     def atomic_forward(self, *, x_active, x_frozen, parity, net, log0=0):
