@@ -2537,3 +2537,34 @@ def test_consecutive_coupling_blocks_hand_their_parts_over():
     assert torch.equal(y, y0) and torch.equal(lj, l0)
     assert torch.equal(xb, x0) and torch.equal(lb, lb0)
     assert float((xb - x).abs().median()) < 1e-4       # (and it is the inverse: the fp32 DistConvertor_ in the middle is ill-conditioned in its tails)
+
+
+def test_posterior_graphed_draws_equal_the_eager_draws():
+    """Posterior.graphed: the net pass of posterior.sample__ / mcmc.sample replayed from a HIP graph (one per batch shape) -- the
+    same draws as the eager pass for the same seed, before and after the parameters change (the graph re-captures itself)."""
+    import normflow__amd as nf
+    from normflow__amd.prior import NormalPrior
+    from normflow__amd.action import ScalarPhi4Action
+    torch.manual_seed(6)
+    shape = (16, 16)
+    mask = EvenOddMask(shape=shape)
+    mk = lambda c: ConvAct(1, c, 3, conv_dim=2, hidden_sizes=[8, 8], acts=['tanh', 'tanh', None])
+    net_ = ModuleList_([AffineCoupling_([mk(2), mk(2)], mask=mask), RQSplineCoupling_([mk(22)], mask=mask, xlim=(-5, 5), ylim=(-5, 5),
+                                                                                     extrap={'left': 'linear', 'right': 'linear'})])
+    net_.to(device=DEV, dtype=torch.float32)
+    prior = NormalPrior(loc=torch.zeros(shape, device=DEV, dtype=torch.float32), scale=torch.ones(shape, device=DEV, dtype=torch.float32))
+    model = nf.Model(net_=net_, prior=prior, action=ScalarPhi4Action(kappa=0.67, m_sq=-4 * 0.67, lambd=0.5))
+    for round_ in range(2):
+        out = []
+        for graphed in (False, True, True):
+            model.posterior.graphed = graphed
+            torch.manual_seed(100 + round_)
+            out.append(model.posterior.sample__(64))
+        for a, b in ((out[0], out[1]), (out[0], out[2])):
+            assert all(torch.equal(s, t) for s, t in zip(a, b))
+        with torch.no_grad():
+            for p in net_.parameters():
+                p.mul_(1.01)
+    model.posterior.graphed = True
+    y = model.mcmc.sample(32)
+    assert y.shape == (32,) + shape and bool(torch.isfinite(y).all())
