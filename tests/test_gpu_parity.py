@@ -1063,7 +1063,11 @@ def test_example_script_runs_with_package_defaults():
 
 
 @pytest.mark.parametrize("shape,B", [((4, 2, 6, 32), 100), ((2, 2, 2, 32), 7), ((8, 8, 8, 32), 3), ((2, 2, 4, 48), 9), ((4, 4, 4, 64), 5),
-                                     ((4, 2, 2, 96), 3), ((8, 4, 4, 48), 4)])
+                                     ((4, 2, 2, 96), 3), ((8, 4, 4, 48), 4),
+                                     # round 3 (tiled item order per XCD, half items): box counts that are not multiples of the tile,
+                                     # rows of 2.5 and 3.5 segments, many boxes along axis 0, whole 4 x 4 tiles, more items than workgroups
+                                     ((2, 6, 4, 48), 5), ((6, 2, 2, 80), 3), ((2, 2, 2, 112), 2), ((12, 2, 2, 32), 11), ((2, 8, 8, 48), 2),
+                                     ((4, 8, 16, 48), 3)])
 def test_split_fp16_fused_last_layer(shape, B):
     """nf_conv_h.hip: the fused last layer with every fp32 product as three fp16 matrix-core products (hidden
     activations are tanh outputs, so |h| <= 1).  Against (a) the fp32 kernels run separately (conv + coupling) and
