@@ -1110,7 +1110,9 @@ def test_split_fp16_fused_last_layer(shape, B):
 
 
 @pytest.mark.parametrize("shape,B", [((4, 2, 6, 32), 40), ((2, 4, 8, 32), 45), ((2, 2, 4, 32), 300), ((2, 2, 4, 48), 30), ((4, 4, 2, 64), 12),
-                                     ((2, 4, 6, 48), 10)])
+                                     ((2, 4, 6, 48), 10),
+                                     # round 3 (columns numbered tile by tile on multi-segment lattices): tile remainders, 2.5 segments
+                                     ((6, 2, 2, 80), 4), ((2, 6, 4, 48), 6), ((8, 8, 2, 48), 3)])
 def test_split_fp16_hidden_layer_and_chain(shape, B):
     """conv_g_kernel (8 -> 8 hidden layer on fp16 (hi, lo) pairs in and out) against the fp64 definition, and the whole
     split chain of a ConvAct stack (first layer writes the pairs, hidden layer, fused last layer) against the fp32
