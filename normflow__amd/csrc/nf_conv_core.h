@@ -74,6 +74,7 @@ struct ConvArgs {
   int accumulate;                // ... add to the output planes instead of overwriting them
   const float *gyout;            // nf_conv_rqs_vjp: cotangent of the coupling's value, (B, V) like xact
   const float *glogj;            // ... and of its log-det, (B)
+  int seg_lo, seg_n;             // nf_conv_g.hip: the launch covers segments seg_lo .. seg_lo + seg_n - 1 of every row (0, 0 = all)
 };
 
 // The power of two that brings a tensor whose largest magnitude has the bits *absmax to [2^12, 2^13): cotangents of a mean

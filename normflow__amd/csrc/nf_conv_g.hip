@@ -78,7 +78,7 @@ __device__ __forceinline__ float act_affine(float a, float c1, float c0, float a
 // (output channel 0 = t, 1 = s; the other six columns carry zero weights) fused with the coupling itself
 // (src/nn/scalar/couplings_.py:123-139): y = t + x e^{-|s|} (1) or x = (y - t) e^{|s|} (2) at the active site of every pair,
 // 0 at the frozen one, and the per-sample log-det partials -- the (B, 2, V/2) parameter tensor never exists in memory.
-template <bool SEGM, int EPI>
+template <bool SEGM, int EPI, bool HK = false>
 __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
   using namespace g2;
   typedef Geo<SEGM> G;
@@ -98,7 +98,8 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
   const int L2 = A.L[2], nstep = L2 >> 1;                       // steps per column; its ring entries are the planes -1 .. L2
   const int L3 = A.L[3], HP = L3 >> 1, NSEG = (HP + 15) >> 4;    // sites / pairs of a row; segments per row (1 when !SEGM)
   const int RB = L3 * 32, HB = L3 * 16, PB = L3 * 8;             // bytes of a row of the pair tensor / its hi block / a parity block
-  const int total = int(A.nitems);                                // B * ncol * NSEG columns (< 2^31: checked by the launcher)
+  const int seg_lo = SEGM ? A.seg_lo : 0, seg_n = SEGM ? (A.seg_n > 0 ? A.seg_n : NSEG) : 1;      // the segments this launch covers
+  const int total = int(A.nitems);                                // B * ncol * seg_n columns (< 2^31: checked by the launcher)
   const int xcd = blockIdx.x & 7, jm = blockIdx.x >> 3;
   auto col_id = [&](int ci) { return (xcd + 8 * ci) * 32 + jm; };
   int ncols_my = 0;
@@ -116,8 +117,8 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
     int gc = col_id(ci);
     hs = 0;
     if (SEGM) {                                // the segment is the fastest index: a row's segments run at the same time
-      hs = gc % NSEG;
-      gc /= NSEG;
+      hs = seg_lo + gc % seg_n;
+      gc /= seg_n;
     }
     b = gc / ncol;
     // columns of a sample are numbered tile by tile (td0 x td1 columns in axes 0, 1, as many -- with their segments -- as an XCD
@@ -165,6 +166,14 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
   const unsigned rowsel = unsigned(((q >> 1) * 4 + (q & 1)) * RBL);
   const unsigned lane_a = rowsel + unsigned((SEGM && ja == 16) ? 1024 + para * 16 : para * 256 + (ja & 15) * 16);
   const unsigned lane_al = lane_a + unsigned((SEGM && ja == 16) ? 32 : 512);       // its lo half
+  // HALF COLUMNS (round 3): the last segment of a 48-, 80-, ... wide row holds 8 pairs; its columns pack the two planes of a step
+  // into ONE tile per cross-section position -- lanes p < 8 plane 2s, lanes p >= 8 plane 2s + 1, pair 16 hs + (p & 7) -- : half
+  // the MFMAs of a wave, the B wave of a pair finishes the tile.  (Not the training form EPI = 3.)
+  // They run in a launch of their own (template parameter HK; the launcher sends the full segments through the plain kernel
+  // first): with both forms in one kernel the register allocation went past 256 and spilled.
+  constexpr bool HALF = SEGM && EPI != 3 && HK;
+  const int psh = p >> 3, pm = p & 7;
+  const int lane_am_delta = int(rowsel + unsigned(para * 256 + (pm + (g >> 1)) * 16)) - int(lane_a);      // (local slot <= 8: the main piece)
   // ---- DMA: wave w copies halo rows 2w and 2w + 1 of every plane; lane l brings slot (16 hs + (l & 15)) mod HP of block l >> 4
   // ([hi | lo][even | odd]) of the row; lanes 0..3 of a second piece bring the 17th slot of the four blocks
   const int hz0 = wave >> 1, hz1a = 2 * (wave & 1);
@@ -251,12 +260,26 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
       const int a = (A.parity + x0 + x1 + te) & 1;
       lane_ok = lane_ok && g == 2 * a;        // the lanes that hold channels 0..3 (t, s, -, -) of the ACTIVE site
       fcol = ((int64_t(b) * A.L[0] + x0) * A.L[1] + x1) * int64_t(L2) * HP + int64_t(te) * HP + (qq < HP ? qq : 0);
-      const int per = ncol * NSEG;            // columns per sample
-      const int gc = col_id(ci);
+      const int per = ncol * NSEG;            // columns per sample (all segments)
+      const int gcl = col_id(ci);             // the launch's own numbering -> the global one [sample][cross-section][segment]
+      const int gc = (gcl / seg_n) * NSEG + hs;
       col_slot = (gc - (gc / per) * per) * 8 + wave + (gc / per) * per * 8;      // sample-major: [sample][column][wave]
     }
     lane_o = unsigned(pair_row_offset(lane_ok ? 2 * qq + (g >> 1) : 0, L3) + (g & 1) * 8);
     ocol = outb + int64_t(b) * sampleB + int64_t(((2 * i0 + (q >> 1)) * A.L[1] + 2 * i1 + (q & 1)) * L2 + te) * RB;
+    if constexpr (HALF) {
+      // lane (p, g) of the merged tile: plane 2s + psh, pair 16 hs + pm; the B wave stores, the A wave's lanes are off
+      const int qh = 16 * hs + pm;
+      lane_ok = isB;
+      if (EPI > 0) {
+        const int x0 = 2 * i0 + (q >> 1), x1 = 2 * i1 + (q & 1);
+        const int a = (A.parity + x0 + x1 + psh) & 1;
+        lane_ok = isB && g == 2 * a;
+        fcol = ((int64_t(b) * A.L[0] + x0) * A.L[1] + x1) * int64_t(L2) * HP + int64_t(psh) * HP + qh;
+      }
+      lane_o = unsigned(pair_row_offset(2 * qh + (g >> 1), L3) + (g & 1) * 8) + unsigned(psh) * unsigned(RB);
+      ocol = outb + int64_t(b) * sampleB + int64_t(((2 * i0 + (q >> 1)) * A.L[1] + 2 * i1 + (q & 1)) * L2) * RB;
+    }
   };
   open_column(0);
   int cci = 0, s = 0;                         // the column's index in my list, the step inside it
@@ -381,8 +404,21 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
       rowa[i] = po + lane_a;
       rowl[i] = po + lane_al;
     }
-    // rows I0 .. I1 of combo offset coff (tap j2 of tile t reads row t + j2)
-    auto fetch = [&](f16x8 (&fh)[4], f16x8 (&fl)[4], int coff, int I0, int I1) {
+    // rows I0 .. I1 of combo offset coff (tap j2 of tile t reads row t + j2); half column: taps H0 .. H1 of the merged tile
+    auto fetch = [&](f16x8 (&fh)[4], f16x8 (&fl)[4], int coff, int I0, int I1, int H0, int H1) {
+      if constexpr (HALF) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          if (i < H0 || i > H1) continue;
+          // this lane's fragment of tap i: plane i (+ 1 for the upper half of the lanes) of the ring window, its own slot
+          // (arithmetic on the lane's plane index, not a select between rowa[i] and rowa[i + 1]: the compiler turned that
+          //  select into a scratch array indexed per lane)
+          const unsigned rm = unsigned(((rbase + i + psh) & (NSLOT - 1)) * PLANE) + unsigned(int(lane_a) + lane_am_delta);
+          fh[i] = *reinterpret_cast<const f16x8 *>(smem_g2 + rm + coff);
+          fl[i] = *reinterpret_cast<const f16x8 *>(smem_g2 + rm + 512 + coff);
+        }
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (i < I0 || i > I1) continue;
@@ -402,6 +438,18 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
       if (NF_G2_ABL & 4) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fh[i]), "v"(fl[i]));
+        return;
+      }
+      if constexpr (HALF) {                    // one merged tile: tap j2 multiplies fragment j2
+#pragma unroll
+        for (int j2 = 0; j2 < 3; ++j2)
+          if (j2 >= J0 && j2 <= J1) am[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[base + j2], fh[j2], am[0], 0, 0, 0);
+#pragma unroll
+        for (int j2 = 0; j2 < 3; ++j2)
+          if (j2 >= J0 && j2 <= J1) ac[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[base + j2], fh[j2], ac[0], 0, 0, 0);
+#pragma unroll
+        for (int j2 = 0; j2 < 3; ++j2)
+          if (j2 >= J0 && j2 <= J1) ac[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[base + j2], fl[j2], ac[0], 0, 0, 0);
         return;
       }
 #pragma unroll
@@ -426,32 +474,32 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
     //  at each MFMA group; the reads of the next combo must issue BEFORE the current combo's MFMAs)
 #define NF_SB __builtin_amdgcn_sched_barrier(0)
     if (!isB) {                                // slices 0..13: combos 0..3 and taps 0, 1 of combo 4
-      fetch(fh0, fl0, combo_off(0), 0, 3);
-      fetch(fh1, fl1, combo_off(1), 0, 3);
+      fetch(fh0, fl0, combo_off(0), 0, 3, 0, 2);
+      fetch(fh1, fl1, combo_off(1), 0, 3, 0, 2);
       NF_SB; mult(fh0, fl0, 0, 0, 2); NF_SB;
       dma_slot(0);
-      fetch(fh0, fl0, combo_off(2), 0, 3);
+      fetch(fh0, fl0, combo_off(2), 0, 3, 0, 2);
       NF_SB; mult(fh1, fl1, 3, 0, 2); NF_SB;
       dma_slot(1);
-      fetch(fh1, fl1, combo_off(3), 0, 3);
+      fetch(fh1, fl1, combo_off(3), 0, 3, 0, 2);
       NF_SB; mult(fh0, fl0, 6, 0, 2); NF_SB;
       dma_slot(2);
-      fetch(fh0, fl0, combo_off(4), 0, 2);
+      fetch(fh0, fl0, combo_off(4), 0, 2, 0, 1);
       NF_SB; mult(fh1, fl1, 9, 0, 2); NF_SB;
       dma_slot(3);
       mult(fh0, fl0, 12, 0, 1);
       NF_SB;
     } else {                                   // slices 14..26: tap 2 of combo 4 and combos 5..8 (local index = global - 14)
-      fetch(fh0, fl0, combo_off(4), 2, 3);
-      fetch(fh1, fl1, combo_off(5), 0, 3);
+      fetch(fh0, fl0, combo_off(4), 2, 3, 2, 2);
+      fetch(fh1, fl1, combo_off(5), 0, 3, 0, 2);
       NF_SB; mult(fh0, fl0, 12 - NSA, 2, 2); NF_SB;
-      fetch(fh0, fl0, combo_off(6), 0, 3);
+      fetch(fh0, fl0, combo_off(6), 0, 3, 0, 2);
       NF_SB; mult(fh1, fl1, 15 - NSA, 0, 2); NF_SB;
       dma_slot(0);
-      fetch(fh1, fl1, combo_off(7), 0, 3);
+      fetch(fh1, fl1, combo_off(7), 0, 3, 0, 2);
       NF_SB; mult(fh0, fl0, 18 - NSA, 0, 2); NF_SB;
       dma_slot(1);
-      fetch(fh0, fl0, combo_off(8), 0, 3);
+      fetch(fh0, fl0, combo_off(8), 0, 3, 0, 2);
       NF_SB; mult(fh1, fl1, 21 - NSA, 0, 2); NF_SB;
       dma_slot(2);
       mult(fh0, fl0, 24 - NSA, 0, 2);
@@ -469,8 +517,9 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) am[t][r] += ac[t][r];
-    *reinterpret_cast<f32x4 *>(smem_g2 + (k & 1) * XBUF + xsend) = isB ? am[0] : am[1];
-    prev = isB ? am[1] : am[0];
+    constexpr bool mh = HALF;                  // (half column: the A wave hands its half of the K sum of the merged tile to B)
+    *reinterpret_cast<f32x4 *>(smem_g2 + (k & 1) * XBUF + xsend) = (isB || mh) ? am[0] : am[1];
+    prev = (isB && !mh) ? am[1] : am[0];
     pout = ocol + unsigned(2 * s) * unsigned(RB);
     plane_o = lane_o;
     plane_ok = lane_ok;
@@ -559,7 +608,23 @@ static int launch_g2(ConvArgs &A, const int32_t *lattice, int64_t B, int epi, hi
   int rc;
   if (segm) {
     constexpr int lds = g2::Geo<true>::LDS_BYTES;
-    rc = epi == 0 ? go(&conv_g2_kernel<true, 0>, lds) : (epi == 1 ? go(&conv_g2_kernel<true, 1>, lds) : (epi == 2 ? go(&conv_g2_kernel<true, 2>, lds) : go(&conv_g2_kernel<true, 3>, lds)));
+    const int nseg = (lattice[3] / 2 + 15) / 16;
+    const int64_t per_seg = A.nitems / nseg;
+    if (epi != 3 && ((lattice[3] / 2) & 15) == 8) {
+      // a last segment of 8 pairs: the full segments through the plain kernel, then the half columns in their packed form
+      rc = NF_OK;
+      if (nseg > 1) {
+        A.seg_lo = 0; A.seg_n = nseg - 1; A.nitems = per_seg * (nseg - 1);
+        rc = epi == 0 ? go(&conv_g2_kernel<true, 0>, lds) : (epi == 1 ? go(&conv_g2_kernel<true, 1>, lds) : go(&conv_g2_kernel<true, 2>, lds));
+      }
+      if (rc == NF_OK) {
+        A.seg_lo = nseg - 1; A.seg_n = 1; A.nitems = per_seg;
+        rc = epi == 0 ? go(&conv_g2_kernel<true, 0, true>, lds) : (epi == 1 ? go(&conv_g2_kernel<true, 1, true>, lds) : go(&conv_g2_kernel<true, 2, true>, lds));
+      }
+    } else {
+      A.seg_lo = 0; A.seg_n = nseg;
+      rc = epi == 0 ? go(&conv_g2_kernel<true, 0>, lds) : (epi == 1 ? go(&conv_g2_kernel<true, 1>, lds) : (epi == 2 ? go(&conv_g2_kernel<true, 2>, lds) : go(&conv_g2_kernel<true, 3>, lds)));
+    }
   } else {
     constexpr int lds = g2::Geo<false>::LDS_BYTES;
     rc = epi == 0 ? go(&conv_g2_kernel<false, 0>, lds) : (epi == 1 ? go(&conv_g2_kernel<false, 1>, lds) : (epi == 2 ? go(&conv_g2_kernel<false, 2>, lds) : go(&conv_g2_kernel<false, 3>, lds)));
