@@ -47,7 +47,10 @@ __device__ __forceinline__ float act_affine_c(float a, float c1, float c0, float
   return __builtin_fmaf(al, __builtin_amdgcn_rcpf(1.0f + t), ga);
 }
 
-// C0 x C1 = rows of the cross-section (2 or 4 each)
+// C0 x C1 = rows of the cross-section (2 or 4 each).  HK (round 3): the launch covers the 8-pair last segment of a 48-, 80-, ... wide
+// row and packs a wave's two rows (w, w + 8 of a 4 x 4 cross-section) into ONE tile -- lanes p < 8 row w, lanes p >= 8 row w + 8,
+// pair 16 hs + (p & 7) --: half the MFMAs and fragment reads; the full segments go through the plain instance first.
+template <bool HK>
 __global__ __launch_bounds__(512, 2) void conv_c2_kernel(ConvArgs A) {
   using namespace c2;
   extern __shared__ __align__(16) unsigned char smem_c2[];
@@ -61,7 +64,8 @@ __global__ __launch_bounds__(512, 2) void conv_c2_kernel(ConvArgs A) {
   const int L2 = A.L[2], L3 = A.L[3];
   const int RB = L3 * 32, HB = L3 * 16;                    // bytes of an output row of the pair tensor / of its hi block
   const int HP = L3 >> 1, NSEG = (HP + 15) >> 4;           // pairs per row; segments per row
-  const int total = int(A.nitems);                        // B * ncol * NSEG columns
+  const int seg_lo = A.seg_lo, seg_n = A.seg_n > 0 ? A.seg_n : NSEG;      // the segments this launch covers
+  const int total = int(A.nitems);                        // B * ncol * seg_n columns
   const int nwg = gridDim.x;
   // my columns: blockIdx, blockIdx + nwg, ...  (a column of this layer reads 4 B and writes 32 B per site: no halo traffic to
   // speak of, so no XCD-aware grouping is needed)
@@ -69,8 +73,8 @@ __global__ __launch_bounds__(512, 2) void conv_c2_kernel(ConvArgs A) {
   const int ncols_my = (total - int(blockIdx.x) + nwg - 1) / nwg;
   auto decode = [&](int ci, int &b, int &i0, int &i1, int &hs) {
     int gc = int(blockIdx.x) + ci * nwg;
-    hs = gc % NSEG;
-    gc /= NSEG;
+    hs = seg_lo + gc % seg_n;
+    gc /= seg_n;
     b = gc / ncol;
     const int c = gc - b * ncol;
     i0 = c / n1;
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(512, 2) void conv_c2_kernel(ConvArgs A) {
   auto open_column = [&](int ci) {
     int b, i0, i1, hs;
     decode(ci, b, i0, i1, hs);
-    const int q = 16 * hs + p;
+    const int q = 16 * hs + (HK ? (p & 7) : p);
     lane_ok = q < HP;
     lane_o = unsigned(pair_row_offset(lane_ok ? 2 * q + (g >> 1) : 0, L3) + (g & 1) * 8);
 #pragma unroll
@@ -239,15 +243,17 @@ __global__ __launch_bounds__(512, 2) void conv_c2_kernel(ConvArgs A) {
           fbase[sl][h] = (j2 == 0 ? poff[0] : (j2 == 1 ? poff[1] : poff[2])) + roff[sl][h];
         }
       __builtin_amdgcn_s_setprio(2);           // four waves share a SIMD: the one that multiplies issues first
+      // HK: this lane's row of the merged tile (its window starts at pair p & 7 of that row)
+      [[maybe_unused]] const int tmerged = (p & 8) ? toff[1] - 32 : toff[0];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < (HK ? 1 : 2); ++t) {
         if (tz[t] < NT) {
 #pragma unroll
           for (int sl = 0; sl < 4; ++sl) {
             union { f16x8 v; unsigned w[4]; } fh, fl;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-              const unsigned char *src = smem_c2 + toff[t] + fbase[sl][h];      // 4-byte aligned: two dword reads
+              const unsigned char *src = smem_c2 + (HK ? tmerged : toff[t]) + fbase[sl][h];      // 4-byte aligned: two dword reads
               fh.w[2 * h] = *reinterpret_cast<const unsigned *>(src);
               fh.w[2 * h + 1] = *reinterpret_cast<const unsigned *>(src + 4);
               fl.w[2 * h] = *reinterpret_cast<const unsigned *>(src + MAXROWS * IROW);
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void conv_c2_kernel(ConvArgs A) {
     // (3) epilogue of my tiles, straight from the accumulators: lane (p, g) holds channels 4 (g & 1) + r of site 2p + (g >> 1)
     if (compute) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < (HK ? 1 : 2); ++t) {
         if (tz[t] < NT) {
           // (the packed forms v_pk_add_f32 / v_pk_fma_f32 / v_cvt_pk_f16_f32 for two channels at a time were measured: 2 % slower)
           f16x4 hi, lo;
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void conv_c2_kernel(ConvArgs A) {
             lo[r] = static_cast<_Float16>(v - static_cast<float>(h0));
           }
           if (lane_ok) {
-            unsigned char *d = ocol[t] + unsigned(z) * unsigned(RB) + lane_o;
+            unsigned char *d = (HK ? ((p & 8) ? ocol[1] : ocol[0]) : ocol[t]) + unsigned(z) * unsigned(RB) + lane_o;
             *reinterpret_cast<f16x4 *>(d) = hi;
             *reinterpret_cast<f16x4 *>(d + HB) = lo;
           }
@@ -346,8 +352,27 @@ extern "C" int nf_conv_first_split16(const void *in, const void *wsplit, const v
     NF_REQUIRE(hipGetDeviceProperties(&prop, dev) == hipSuccess, "nf_conv_first_split16: no device properties");
     ncu = prop.multiProcessorCount;
   }
-  int64_t grid = int64_t(2) * ncu;             // two persistent workgroups per CU
-  if (grid > A.nitems) grid = A.nitems;
-  hipLaunchKernelGGL(conv_c2_kernel, dim3(unsigned(grid)), dim3(512), c2::LDS_BYTES, stream, A);
+  const int nseg = (lattice[3] / 2 + 15) / 16;
+  const int64_t per_seg = A.nitems / nseg;
+  auto go = [&](bool hk) {
+    int64_t grid = int64_t(2) * ncu;           // two persistent workgroups per CU
+    if (grid > A.nitems) grid = A.nitems;
+    if (hk)
+      hipLaunchKernelGGL(conv_c2_kernel<true>, dim3(unsigned(grid)), dim3(512), c2::LDS_BYTES, stream, A);
+    else
+      hipLaunchKernelGGL(conv_c2_kernel<false>, dim3(unsigned(grid)), dim3(512), c2::LDS_BYTES, stream, A);
+  };
+  if (((lattice[3] / 2) & 15) == 8 && A.box[0] == 4 && A.box[1] == 4) {
+    // a last segment of 8 pairs: the full segments through the plain kernel, the half columns packed two rows to a tile
+    if (nseg > 1) {
+      A.seg_lo = 0; A.seg_n = nseg - 1; A.nitems = per_seg * (nseg - 1);
+      go(false);
+    }
+    A.seg_lo = nseg - 1; A.seg_n = 1; A.nitems = per_seg;
+    go(true);
+  } else {
+    A.seg_lo = 0; A.seg_n = nseg;
+    go(false);
+  }
   return check_launch("conv split-fp16 first-layer kernel");
 }
