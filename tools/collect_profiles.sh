@@ -8,7 +8,7 @@ TAG=${1:-r03}
 P=gpurun_out/${TAG}p
 mkdir -p $P
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python bench.py --steps 3 --warmup 1 > $P/bench.json 2> $P/bench.err
+python bench.py --steps 3 --warmup 2 > $P/bench.json 2> $P/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs > $P/bench_under_rocprof.json 2> $P/trace.err
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $P/$c -o run -- python3 tools/kbench.py --reps 2 > $P/$c.log 2>&1
