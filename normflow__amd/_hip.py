@@ -78,6 +78,7 @@ PROTOTYPES = {
     "nf_conv_dgrad_split16": (_I, [_P, _P, _P, _P, _I64, C.POINTER(C.c_int32), _P, _I, _I, _P]),
     "nf_absmax_bits": (_I, [_P, _I64, _P, _P]),
     "nf_conv_last_logits_split16": (_I, [_P, _I, _P, _P, _P, _I64, C.POINTER(C.c_int32), _I, _P, _P]),
+    "nf_conv_last_logits_split16_acc": (_I, [_P, _I, _P, _P, _P, _I64, C.POINTER(C.c_int32), _I, _P, _I, _P]),
     "nf_expand_pairs": (_I, [_P, _P, _I64, C.POINTER(C.c_int32), _I, _I, _P]),
     "nf_gather_pad": (_I, [_P, _P, _P, _I64, _I64, _I, _P]),
     "nf_conv_wgrad_sites_supported": (_I, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I]),
@@ -1066,6 +1067,60 @@ def conv_last_logits_split16(x, weight, bias, parity):
     _check(lib.nf_conv_last_logits_split16(_ptr(src), is16, _ptr(wsp), _ptr(b), _ptr(out), B, lat4, int(parity), _ptr(bits),
                                            _stream()), "nf_conv_last_logits_split16")
     return out
+
+
+def pack_wide_split16(w1, b1, w2, b2, w3, b3):
+    """Weights of a stack 1 -> h -> h -> C with 8 < h <= 16 (3^4 kernels) for `conv_wide_logits_split16`: the hidden channels
+    zero-padded to 16 and cut into two groups of 8 -- [first-layer fragments x 2, biases x 2], [two-site fragments of the four
+    8 x 8 blocks of the hidden layer, biases x 2], [last-layer fragments x 2, bias]."""
+    h, cout = w1.shape[0], w3.shape[0]
+    f = lambda t: t.detach().float()
+    w1p = f(w1).new_zeros((16, 1, 3, 3, 3, 3)); w1p[:h] = f(w1)
+    w2p = f(w2).new_zeros((16, 16, 3, 3, 3, 3)); w2p[:h, :h] = f(w2)
+    w3p = f(w3).new_zeros((cout, 16, 3, 3, 3, 3)); w3p[:, :h] = f(w3)
+    padb = lambda b, n: None if b is None else torch.nn.functional.pad(f(b), (0, n - b.shape[0]))
+    b1p, b2p = padb(b1, 16), padb(b2, 16)
+    cut = lambda b, g: None if b is None else b[8 * g:8 * g + 8].contiguous()
+    first = [(pack_conv_weight_split16_first(w1p[8 * g:8 * g + 8].contiguous()), cut(b1p, g)) for g in (0, 1)]
+    hidden = [[pack_conv_weight_split16_two_site(w2p[8 * go:8 * go + 8, 8 * gi:8 * gi + 8].contiguous()) for gi in (0, 1)] for go in (0, 1)]
+    last = [pack_conv_weight_split16(w3p[:, 8 * gi:8 * gi + 8].contiguous()) for gi in (0, 1)]
+    return first, (hidden, [cut(b2p, 0), cut(b2p, 1)]), (last, None if b3 is None else f(b3).contiguous()), cout
+
+
+def conv_wide_logits_split16(x, packed, act1, parity):
+    """The raw output (B, C, V/2) at the active sites of a ConvAct stack 1 -> h -> h -> C with hidden widths 9 .. 16 and tanh
+    hidden activations on a 4-D lattice, composed from the split-fp16 kernels in groups of 8 channels: the first layer twice
+    (nf_conv_first_split16), the four 8 x 8 blocks of the hidden layer through nf_conv_dgrad_split16 (fp32 planes out, the second
+    block of a group added to the first, tanh of the sum) + nf_planes_to_split16, the last layer twice (nf_conv_last_logits_split16,
+    the second group added).  x: (B, 1, *L) fp32.  Twice as fast as the fp32 MFMA kernels on this shape (tools/hidden16_bench.py)."""
+    lib = load()
+    first, (hidden, hb), (last, b3), cout = packed
+    B = x.shape[0]
+    lattice = tuple(x.shape[2:])
+    lat4 = (C.c_int32 * 4)(*lattice)
+    V = x[0, 0].numel()
+    x = x.contiguous()
+    tanh = ACT_CODES['tanh']
+    h1 = []
+    for wsp, b in first:
+        out = torch.empty((B, V, 16), dtype=torch.float16, device=x.device)
+        _check(lib.nf_conv_first_split16(_ptr(x), _ptr(wsp), _ptr(b), _ptr(out), B, lat4, int(act1), _stream()), "nf_conv_first_split16")
+        h1.append(out)
+    h2 = []
+    z = torch.empty((B, 8) + lattice, dtype=torch.float32, device=x.device)
+    for go in (0, 1):
+        for gi in (0, 1):
+            _check(lib.nf_conv_dgrad_split16(_ptr(h1[gi]), _ptr(hidden[go][gi]), _ptr(hb[go]) if gi == 0 else None, _ptr(z), B, lat4, None,
+                                             int(gi > 0), tanh if gi == 1 else 0, _stream()), "nf_conv_dgrad_split16")
+        out = torch.empty((1, B, V, 16), dtype=torch.float16, device=x.device)
+        _check(lib.nf_planes_to_split16(_ptr(z), _ptr(out), None, B, 8, lat4, -1, _stream()), "nf_planes_to_split16")
+        h2.append(out)
+    del h1
+    logits = torch.empty((B, 46, V // 2), dtype=torch.float32, device=x.device)
+    for gi in (0, 1):
+        _check(lib.nf_conv_last_logits_split16_acc(_ptr(h2[gi]), 1, _ptr(last[gi]), _ptr(b3) if gi == 0 else None, _ptr(logits), B, lat4,
+                                                   int(parity), None, int(gi > 0), _stream()), "nf_conv_last_logits_split16_acc")
+    return logits if cout == 46 else logits[:, :cout].contiguous()
 
 
 class ConvFn(torch.autograd.Function):

@@ -336,8 +336,9 @@ __global__ __launch_bounds__(512, 2) void conv_g2_kernel(ConvArgs A) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = (prev[r] + pa[r]) * descale + bv4[r];
-          if (A.act == kActTanh) v = tanh_affine(v, 2.885390081777927f, 0.f);
-          d[int64_t(r) * A.V] = A.accumulate ? pold[r] + v : v;      // (the old values were requested a step ago)
+          if (A.accumulate) v += pold[r];                            // (the old values were requested a step ago)
+          if (A.act == kActTanh) v = tanh_affine(v, 2.885390081777927f, 0.f);      // of the SUM: the last group pass of a layer with more than 8 input channels
+          d[int64_t(r) * A.V] = v;
         }
       }
     } else {

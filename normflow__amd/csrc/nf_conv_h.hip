@@ -628,7 +628,14 @@ __global__ __launch_bounds__(256, 1) void conv_h_kernel(ConvArgs A) {
         const int64_t pair = pair_of(b, o, pass, pok);
         if (pok) {
           float *d = outp + (int64_t(b) * A.cout) * Vh + (pair - int64_t(b) * Vh);
-          if (A.cout == C) {
+          if (A.accumulate) {                  // (a second group of 8 input channels adds to the first one's logits:
+            float old[C];                      //  all loads in flight, then the stores)
+#pragma unroll
+            for (int c = 0; c < C; ++c) old[c] = c < A.cout ? d[int64_t(c) * Vh] : 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+              if (c < A.cout) d[int64_t(c) * Vh] = old[c] + ptl[c * PTS + u];
+          } else if (A.cout == C) {
 #pragma unroll
             for (int c = 0; c < C; ++c) d[int64_t(c) * Vh] = ptl[c * PTS + u];
           } else {
@@ -919,9 +926,25 @@ using namespace nf;
 // differentiates the spline separately (reference: src/nn/scalar/modules.py:120-145 under Fitter.step).  in: fp32 channel
 // planes (B, 8, V) (fastest axis of 32 sites) or, with in_split16, the (B, V, 16) pair tensor; absmax_bits (or NULL): the
 // input is / gets scaled by the matching power of two (nf_absmax_bits), the logits are descaled.  wsplit: NF_WLAYOUT_SPLIT16.
+static int last_logits_split16(const void *in, int in_split16, const void *wsplit, const void *bias, void *logits, int64_t B,
+                               const int32_t *lattice, int active_parity, const void *absmax_bits, int accumulate, void *stream_);
+
 extern "C" int nf_conv_last_logits_split16(const void *in, int in_split16, const void *wsplit, const void *bias, void *logits,
                                            int64_t B, const int32_t *lattice, int active_parity, const void *absmax_bits,
                                            void *stream_) {
+  return last_logits_split16(in, in_split16, wsplit, bias, logits, B, lattice, active_parity, absmax_bits, 0, stream_);
+}
+
+// ... the same, ADDED to the logits already there when `accumulate`: the second group of 8 input channels of a 16 -> 46 layer
+// (hidden width 16 on the split-fp16 kernels: normflow__amd/_hip.py, conv_wide_logits_split16)
+extern "C" int nf_conv_last_logits_split16_acc(const void *in, int in_split16, const void *wsplit, const void *bias, void *logits,
+                                               int64_t B, const int32_t *lattice, int active_parity, const void *absmax_bits,
+                                               int accumulate, void *stream_) {
+  return last_logits_split16(in, in_split16, wsplit, bias, logits, B, lattice, active_parity, absmax_bits, accumulate, stream_);
+}
+
+static int last_logits_split16(const void *in, int in_split16, const void *wsplit, const void *bias, void *logits, int64_t B,
+                               const int32_t *lattice, int active_parity, const void *absmax_bits, int accumulate, void *stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   NF_REQUIRE(in && wsplit && logits && lattice, "nf_conv_last_logits_split16: NULL pointer");
   NF_REQUIRE(B >= 0, "nf_conv_last_logits_split16: negative batch");
@@ -934,6 +957,7 @@ extern "C" int nf_conv_last_logits_split16(const void *in, int in_split16, const
   A.parity = active_parity & 1;
   A.in_split16 = in_split16 ? 1 : 0;
   A.gscale_bits = static_cast<const unsigned *>(absmax_bits);
+  A.accumulate = accumulate ? 1 : 0;
   const int pr = launch_conv_h(A, B, 3, stream, false);
   if (pr == 0) {
     set_error("nf_conv_last_logits_split16: layer not supported (4-D lattice, even extents, fastest axis 32 + 16 n sites; fp32 planes need 32)");

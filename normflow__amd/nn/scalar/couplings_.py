@@ -390,6 +390,11 @@ class RQSplineCoupling_(Coupling_):
                                              _hip.make_rqs_opts((n_out + 2) // 3, self.xlim, self.ylim, self.extrap, _hip.LAYOUT_PAIR))
         if small is not None:
             return small
+        # hidden widths 9 .. 16: the stack runs the split-fp16 kernels in groups of 8 channels and hands the logits to the coupling
+        # kernel (ConvAct.forward_active -> _hip.conv_wide_logits_split16): twice as fast as the fp32 kernels fused
+        if (hasattr(net, '_wide_plan') and x_active.dtype == torch.float32 and x_active.dim() == 5
+                and net._wide_plan(self.preprocess_fz(x_frozen[:1])) is not None):
+            return None
         # knots_len 4 / 8 / 16 fuse on every kernel; any other knots_len <= 16 only on the split-fp16 chain (nf_conv_h.hip)
         any_kernel = bool(_hip.load().nf_conv_rqs_supported(n_out, (n_out + 2) // 3))
         if not any_kernel and not hasattr(net, '_fuse_plan'):

@@ -317,7 +317,45 @@ class ConvAct(torch.nn.Sequential):
         coordinate sum has parity `active_parity`.  None if the fused path does not apply."""
         if self.conv_kwargs.get('pre_act') is not None or x.shape[-1] % 2:
             return None
+        wide = self._wide_plan(x)
+        if wide is not None:
+            return _hip.conv_wide_logits_split16(x, wide[0], wide[1], active_parity)
         return self._run_fused(x, compact_parity=active_parity)
+
+    def _wide_plan(self, x):
+        """(packed weights, first activation) when this stack is 1 -> h -> h -> C with 8 < h <= 16, 3^4 circular kernels, tanh
+        hidden activations (the first may be logistic) and fp16-range weights, on a lattice the split-fp16 kernels take, under
+        no_grad: `_hip.conv_wide_logits_split16` composes it from those kernels in groups of 8 channels.  Cached per parameter
+        version.  None otherwise (the fp32 MFMA kernels run the stack)."""
+        import ctypes as C
+        if (torch.is_grad_enabled() or x.dim() != 6 or x.shape[1] != 1 or x.dtype != torch.float32 or not x.is_cuda
+                or self.conv_kwargs['conv_dim'] != 4):
+            return None
+        plan = self._plan()
+        T, S = _hip.ACT_CODES['tanh'], _hip.ACT_CODES['expit']
+        if plan is None or len(plan) != 3 or plan[0][1] not in (T, S) or plan[1][1] != T or plan[2][1] != 0:
+            return None
+        wbs = [self._wb(conv) for conv, _ in plan]
+        (w1, b1), (w2, b2), (w3, b3) = wbs
+        h = w1.shape[0]
+        if (not 8 < h <= 16 or w1.shape[1] != 1 or tuple(w2.shape[:2]) != (h, h) or w3.shape[1] != h or w3.shape[0] > 46
+                or w1.dtype != torch.float32 or any(tuple(w.shape[2:]) != (3, 3, 3, 3) for w, _ in wbs)):
+            return None
+        lib = _hip.load()
+        lat4 = (C.c_int32 * 4)(*x.shape[2:])
+        k4 = (C.c_int32 * 4)(3, 3, 3, 3)
+        if (not lib.nf_get_option(_hip.OPT_SPLIT16) or not lib.nf_conv_split16_supported(lat4, k4, 8, 8, T)
+                or not lib.nf_conv_first_split16_supported(lat4, k4, 8, plan[0][1]) or not lib.nf_conv_rqs_split16_supported(lat4, 46, 16)):
+            return None
+        if not all(_hip._weights_fit_fp16(w) for w, _ in wbs):
+            return None
+        ver = tuple((w._version, w.data_ptr(), None if b is None else (b._version, b.data_ptr())) for w, b in wbs)
+        hit = self.__dict__.get('_wide16')
+        if hit is None or hit[0] != ver:
+            with torch.no_grad():
+                hit = (ver, _hip.pack_wide_split16(w1, b1, w2, b2, w3, b3))
+            self.__dict__['_wide16'] = hit
+        return hit[1], plan[0][1]
 
 
 class LinearAct(torch.nn.Sequential):
