@@ -491,13 +491,13 @@ int nf_conv_dgrad_split16(const void *in16, const void *wsplit, const void *bias
 int nf_conv_last_logits_split16(const void *in, int in_split16, const void *wsplit, const void *bias, void *logits,
                                 int64_t B, const int32_t *lattice, int active_parity, const void *absmax_bits,
                                 void *stream);
-/* ... the same, ADDED to the logits already in `logits` when accumulate != 0 (bias NULL then): the second group of 8 input
- * channels of a 16 -> 3m-2 layer -- hidden width 16 on the split-fp16 kernels (reference: modules.py:68-154 leaves the hidden
+/* ... the same for any cout <= 46 (logits (B, cout, V/2); weights still packed to 48 columns), ADDED to the logits already in
+ * `logits` when accumulate != 0 (bias NULL then): the second group of 8 input channels of a 16 -> cout layer -- hidden width 16 on the split-fp16 kernels (reference: modules.py:68-154 leaves the hidden
  * widths free); normflow__amd/_hip.py, conv_wide_logits_split16 composes the stack 1 -> 16 -> 16 -> 3m-2 from
  * nf_conv_first_split16 x 2, nf_conv_dgrad_split16 x 4 (+ nf_planes_to_split16 x 2) and this entry x 2. */
 int nf_conv_last_logits_split16_acc(const void *in, int in_split16, const void *wsplit, const void *bias, void *logits,
                                     int64_t B, const int32_t *lattice, int active_parity, const void *absmax_bits,
-                                    int accumulate, void *stream);
+                                    int accumulate, int cout, void *stream);
 
 /* nf_expand_pairs: a pair-compact tensor (rows, V/2) -- the layout the active-site-only conv output and its cotangent use --
  * to the full lattice (rows, V), zeros at the sites of the other parity; rows = B * channels; lattice[3] even. */

@@ -78,7 +78,7 @@ PROTOTYPES = {
     "nf_conv_dgrad_split16": (_I, [_P, _P, _P, _P, _I64, C.POINTER(C.c_int32), _P, _I, _I, _P]),
     "nf_absmax_bits": (_I, [_P, _I64, _P, _P]),
     "nf_conv_last_logits_split16": (_I, [_P, _I, _P, _P, _P, _I64, C.POINTER(C.c_int32), _I, _P, _P]),
-    "nf_conv_last_logits_split16_acc": (_I, [_P, _I, _P, _P, _P, _I64, C.POINTER(C.c_int32), _I, _P, _I, _P]),
+    "nf_conv_last_logits_split16_acc": (_I, [_P, _I, _P, _P, _P, _I64, C.POINTER(C.c_int32), _I, _P, _I, _I, _P]),
     "nf_expand_pairs": (_I, [_P, _P, _I64, C.POINTER(C.c_int32), _I, _I, _P]),
     "nf_gather_pad": (_I, [_P, _P, _P, _I64, _I64, _I, _P]),
     "nf_conv_wgrad_sites_supported": (_I, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _I]),
@@ -1116,11 +1116,11 @@ def conv_wide_logits_split16(x, packed, act1, parity):
         _check(lib.nf_planes_to_split16(_ptr(z), _ptr(out), None, B, 8, lat4, -1, _stream()), "nf_planes_to_split16")
         h2.append(out)
     del h1
-    logits = torch.empty((B, 46, V // 2), dtype=torch.float32, device=x.device)
+    logits = torch.empty((B, cout, V // 2), dtype=torch.float32, device=x.device)
     for gi in (0, 1):
         _check(lib.nf_conv_last_logits_split16_acc(_ptr(h2[gi]), 1, _ptr(last[gi]), _ptr(b3) if gi == 0 else None, _ptr(logits), B, lat4,
-                                                   int(parity), None, int(gi > 0), _stream()), "nf_conv_last_logits_split16_acc")
-    return logits if cout == 46 else logits[:, :cout].contiguous()
+                                                   int(parity), None, int(gi > 0), int(cout), _stream()), "nf_conv_last_logits_split16_acc")
+    return logits
 
 
 class ConvFn(torch.autograd.Function):

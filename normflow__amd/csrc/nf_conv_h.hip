@@ -927,24 +927,25 @@ using namespace nf;
 // planes (B, 8, V) (fastest axis of 32 sites) or, with in_split16, the (B, V, 16) pair tensor; absmax_bits (or NULL): the
 // input is / gets scaled by the matching power of two (nf_absmax_bits), the logits are descaled.  wsplit: NF_WLAYOUT_SPLIT16.
 static int last_logits_split16(const void *in, int in_split16, const void *wsplit, const void *bias, void *logits, int64_t B,
-                               const int32_t *lattice, int active_parity, const void *absmax_bits, int accumulate, void *stream_);
+                               const int32_t *lattice, int active_parity, const void *absmax_bits, int accumulate, int cout, void *stream_);
 
 extern "C" int nf_conv_last_logits_split16(const void *in, int in_split16, const void *wsplit, const void *bias, void *logits,
                                            int64_t B, const int32_t *lattice, int active_parity, const void *absmax_bits,
                                            void *stream_) {
-  return last_logits_split16(in, in_split16, wsplit, bias, logits, B, lattice, active_parity, absmax_bits, 0, stream_);
+  return last_logits_split16(in, in_split16, wsplit, bias, logits, B, lattice, active_parity, absmax_bits, 0, h::C, stream_);
 }
 
-// ... the same, ADDED to the logits already there when `accumulate`: the second group of 8 input channels of a 16 -> 46 layer
-// (hidden width 16 on the split-fp16 kernels: normflow__amd/_hip.py, conv_wide_logits_split16)
+// ... the same for any cout <= 46 (logits (B, cout, V/2)), ADDED to the logits already there when `accumulate`: the second group of
+// 8 input channels of a 16 -> cout layer (hidden width 16 on the split-fp16 kernels: normflow__amd/_hip.py, conv_wide_logits_split16)
 extern "C" int nf_conv_last_logits_split16_acc(const void *in, int in_split16, const void *wsplit, const void *bias, void *logits,
                                                int64_t B, const int32_t *lattice, int active_parity, const void *absmax_bits,
-                                               int accumulate, void *stream_) {
-  return last_logits_split16(in, in_split16, wsplit, bias, logits, B, lattice, active_parity, absmax_bits, accumulate, stream_);
+                                               int accumulate, int cout, void *stream_) {
+  NF_REQUIRE(cout >= 1 && cout <= h::C, "nf_conv_last_logits_split16_acc: cout outside [1, 46]");
+  return last_logits_split16(in, in_split16, wsplit, bias, logits, B, lattice, active_parity, absmax_bits, accumulate, cout, stream_);
 }
 
 static int last_logits_split16(const void *in, int in_split16, const void *wsplit, const void *bias, void *logits, int64_t B,
-                               const int32_t *lattice, int active_parity, const void *absmax_bits, int accumulate, void *stream_) {
+                               const int32_t *lattice, int active_parity, const void *absmax_bits, int accumulate, int cout, void *stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   NF_REQUIRE(in && wsplit && logits && lattice, "nf_conv_last_logits_split16: NULL pointer");
   NF_REQUIRE(B >= 0, "nf_conv_last_logits_split16: negative batch");
@@ -953,7 +954,7 @@ static int last_logits_split16(const void *in, int in_split16, const void *wspli
   A.V = 1;
   for (int mu = 0; mu < 4; ++mu) { A.L[mu] = lattice[mu]; A.k[mu] = 3; A.V *= lattice[mu]; }
   A.in = in; A.wfrag = wsplit; A.bias = bias; A.out = logits;
-  A.cin = 8; A.cout = h::C;
+  A.cin = 8; A.cout = cout;
   A.parity = active_parity & 1;
   A.in_split16 = in_split16 ? 1 : 0;
   A.gscale_bits = static_cast<const unsigned *>(absmax_bits);

@@ -2616,3 +2616,32 @@ def test_hidden_width_up_to_16_on_the_split_fp16_kernels(hidden, m, shape, parit
     ey, el = rel(y, yo), rel(lj, lo)
     parity_report(f"hidden width {hidden}, m={m} {shape}", "y / logJ vs fp64 oracle", max(ey, el), 1e-5)
     assert ey <= 1e-5 and el <= 1e-5
+
+
+def test_hidden_width_16_affine_coupling_on_the_split_fp16_kernels():
+    """The same composition under an AffineCoupling_ (net 1 -> 16 -> 16 -> 2: the logits tensor is (B, 2, V/2)): == the exact
+    fp32-product path and the fp64 oracle."""
+    torch.manual_seed(33)
+    shape = (2, 2, 4, 48)
+    nets = [ConvAct(1, 2, 3, conv_dim=4, hidden_sizes=[16, 16], acts=['tanh', 'tanh', None]) for _ in range(2)]
+    mask = EvenOddMask(shape=shape)
+    cpl = AffineCoupling_(nets, mask=mask).to(DEV, torch.float32)
+    x = torch.randn((3,) + shape, device=DEV, dtype=torch.float32)
+    with torch.no_grad():
+        assert nets[0]._wide_plan(x.unsqueeze(1)) is not None
+        y, lj = cpl(x)
+        xb, lb = cpl.backward(y, lj)
+        with _hip.options(split16=False):
+            y32, lj32 = cpl(x)
+    assert rel(y, y32) <= 1e-5 and rel(lj, lj32) <= 1e-5
+    assert rel(xb, x) <= 1e-5 and float(lb.abs().max()) <= 1e-4
+    xo = x.double().cpu()
+    parts = [xo * O.channel_mask(shape, 0), xo * O.channel_mask(shape, 1)]
+    lo = torch.zeros(3, dtype=torch.float64, device='cpu')
+    for k, net in enumerate(nets):
+        p = k % 2
+        convs = [mod for mod in net if hasattr(mod, 'weight')]
+        layers = [(c.weight.detach().double().cpu(), c.bias.detach().double().cpu()) for c in convs]
+        out = O.conv_act(parts[1 - p].unsqueeze(1), layers, ['tanh', 'tanh', None])
+        parts[p], lo = O.affine_coupling_atom(parts[p], out, O.channel_mask(shape, p), log0=lo)
+    assert rel(y, parts[0] + parts[1]) <= 1e-5 and rel(lj, lo) <= 1e-5
