@@ -42,8 +42,8 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 / bf16 MFMA peak (task statement: ~2
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="batch per GPU (weak scaling) = global batch of the strong-scaling leg")
     ap.add_argument("--lattice", type=str, default="32,32,32,32")
     ap.add_argument("--layers", type=int, default=8)
